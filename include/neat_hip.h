@@ -1,0 +1,155 @@
+/* libneat_hip.so -- C ABI of the MI355X (gfx950) kernels behind NEAT's test-time-adaptation path.
+ *
+ * The reference (hhc1997/NEAT) has no native layer: its "kernels" are ATen ops reached from Python
+ * (SURVEY.md §2c).  Each entry point below replaces the ATen call site(s) named in its comment
+ * (paths relative to the reference's src/).  INTEGRATION.md shows the ctypes stubs the reference
+ * would add to bind them.
+ *
+ * Conventions
+ *  - Every pointer is a raw DEVICE address (tensor.data_ptr()); buffers are contiguous, row-major and
+ *    owned by the caller, including workspaces.  The library never allocates or frees device memory.
+ *  - bf16 values are passed as uint16_t bit patterns.
+ *  - Every call enqueues on `stream` (a hipStream_t passed as void*) and returns without synchronising.
+ *  - Return value: 0 = OK, negative = error (enum below); neat_last_error() returns the message of
+ *    the calling thread's last failure.  No C++ exception crosses the boundary.
+ */
+#ifndef NEAT_HIP_H
+#define NEAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    NEAT_OK = 0,
+    NEAT_ERR_SHAPE = -1,       /* shape / alignment not supported by the kernel */
+    NEAT_ERR_ARG = -2,         /* null pointer or invalid enum */
+    NEAT_ERR_HIP = -3,         /* HIP runtime error at launch */
+    NEAT_ERR_COMM = -4         /* collective error */
+};
+
+/* GEMM epilogues (neat_gemm_bf16) */
+enum {
+    NEAT_EPI_BF16 = 0,           /* out0(bf16) = acc                      (dgrad GEMMs)                 */
+    NEAT_EPI_BIAS_BF16 = 1,      /* out0(bf16) = acc + bias[n]            (attn in_proj)                */
+    NEAT_EPI_BIAS_RES_F32 = 2,   /* out0(f32)  = acc + bias[n] + res[m,n] (out_proj / c_proj + residual)*/
+    NEAT_EPI_BIAS_GELU = 3,      /* out0(bf16) = h = acc + bias[n]; out1(bf16) = QuickGELU(h)  (c_fc)   */
+    NEAT_EPI_GELU_BWD = 4,       /* out0(bf16) = acc * QuickGELU'(aux[m,n]), aux bf16 = saved h         */
+    NEAT_EPI_F32 = 5             /* out0(f32)  = acc                      (patch embedding)             */
+};
+
+const char* neat_version(void);
+const char* neat_last_error(void);
+
+/* ---- LayerNorm: F.layer_norm at open_clip/transformer.py:24-30 (eps inside sqrt, biased var) ---- */
+/* x f32 [rows,cols] -> y bf16 [rows,cols], mean/rstd f32 [rows] (either may be NULL).
+ * y_f32 (optional, may be NULL) receives the fp32 result instead of/in addition to y. */
+int neat_ln_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y, float* y_f32,
+                float* mean, float* rstd, int rows, int cols, float eps, void* stream);
+/* Backward.  dy bf16 [rows,cols]; dres f32 (may be NULL) is the residual-branch gradient that is added
+ * to the LN data gradient: dx = dres + LN'(dy).  dx_f32 / dx_bf16 outputs (either may be NULL; dx_f32
+ * may alias dres).  partial f32 [nblk, 2, cols] receives per-block sums of dy*xhat and dy
+ * (nblk = neat_ln_bwd_blocks(rows)); pass NULL to skip parameter gradients (ln_final). */
+int neat_ln_bwd_blocks(int rows);
+int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
+                const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* partial,
+                int rows, int cols, void* stream);
+/* dgamma[c] (+)= sum_b partial[b,0,c]; dbeta[c] (+)= sum_b partial[b,1,c]  (fixed order -> deterministic) */
+int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, float* dgamma, float* dbeta,
+                         int accumulate, void* stream);
+
+/* ---- bf16 MFMA GEMM: nn.Linear / MHA projections, open_clip/transformer.py:209-213,227-229 ---- */
+/* out[M,N] = epilogue(A[M,K] * W[N,K]^T).  A, W bf16, K-contiguous; K % 64 == 0, N % 16 == 0.
+ * bias f32 [N]; res f32 [M,N] (may alias out0); aux bf16 [M,N].  Unused pointers may be NULL. */
+int neat_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, const float* res,
+                   const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
+                   void* stream);
+
+/* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
+/* qkv bf16 [nseq*L, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [nseq*L, C];
+ * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL). */
+int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads,
+                  int causal, void* stream);
+/* dout bf16 [nseq*L, C] -> dqkv bf16 [nseq*L, 3*C] */
+int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq,
+                  int L, int heads, int causal, void* stream);
+
+/* ---- text embedding: nn.Embedding + positional add, open_clip/model.py:272-274 ---- */
+int neat_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* x, int nseq,
+                   int L, int C, int vocab, void* stream);
+/* argmax over each token row (EOT position), open_clip/transformer.py:555-558; first max wins */
+int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int L, void* stream);
+
+/* ---- pooled head: ln_final/ln_post on the pooled row -> @ projection -> F.normalize
+ *      open_clip/model.py:278-286 (text), open_clip/transformer.py:538-542 + model.py:267 (vision) ---- */
+/* x f32 [nseq*L, C]; row index per sequence (NULL -> row 0 = class token); proj f32 [C, D].
+ * Outputs: feat f32 [nseq, D] (normalised iff normalize), and for backward: xe f32 [nseq,C] (pooled rows),
+ * mean/rstd [nseq], nrm [nseq] (L2 norm before clamping).  Backward-only outputs may be NULL. */
+int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,
+                       const float* proj, float* feat, float* xe, float* mean, float* rstd, float* nrm,
+                       int nseq, int L, int C, int D, int normalize, float eps, void* stream);
+/* dfeat f32 [nseq, D] -> gradient rows scattered into dx_f32 / dx_bf16 [nseq*L, C] (must be zeroed by the
+ * caller); ln_final itself is not adapted (open_clip/factory.py:405-407). */
+int neat_pool_proj_bwd(const float* dfeat, const float* feat, const float* nrm, const float* xe,
+                       const float* mean, const float* rstd, const float* gamma, const float* proj,
+                       const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, int nseq, int L, int C,
+                       int D, int normalize, void* stream);
+
+/* ---- vision stem: conv1 (stride = kernel) as a GEMM, open_clip/transformer.py:362,503-513 ---- */
+/* images f32 NCHW [n,3,H,W] -> patches bf16 [n*gh*gw, Kpad], (c,kh,kw) order, zero padded to Kpad */
+int neat_patchify(const float* images, uint16_t* patches, int n, int H, int W, int patch, int Kpad,
+                  void* stream);
+/* x[b,0]=cls+pos[0]; x[b,1+p]=patch_emb[b,p]+pos[1+p]; then ln_pre -> x f32 [n*(P+1), C] */
+int neat_vision_embed(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
+                      const float* beta, float* x, int n, int P, int C, float eps, void* stream);
+/* VideoCLIP.encode_video pooling, utils/video_utils/model.py:62-74,90-91: feat f32 [n*F, D] (already
+ * per-frame normalised) -> out[n, D] = normalize(mean_f feat) */
+int neat_frame_mean_norm(const float* feat, float* out, int n, int F, int D, void* stream);
+
+/* ---- coarse alignment, train_TTA.py:31-42 ---- */
+/* q,pos,neg f32 [B,D]; G f32 [N,D].  S_out f32 [B,N] = q G^T; idx_out i32 [B] = argmax_j
+ * (pos G^T)(1-relu(neg G^T)) (first max); coarse_out f32 [B,D] = G[idx].  ws f32 workspace of
+ * neat_coarse_ws_floats(B,N) floats. */
+long neat_coarse_ws_floats(int B, int N);
+int neat_coarse_align(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
+                      int32_t* idx_out, float* coarse_out, float* ws, int B, int N, int D, void* stream);
+
+/* ---- TTA loss forward + gradient, train_TTA.py:138-143 with :45-48, :53-65, :77-91 ---- */
+/* text,pos,inv f32 [Bl,D] are this rank's rows [row0,row0+Bl) of the global batch; text_all/coarse_all
+ * f32 [B,D] are all B rows (== text/coarse when single-GPU).  losses f32 [3] = entropy, sr, triplet of
+ * the GLOBAL batch (every rank computes the same value); dtext,dpos,dinv f32 [Bl,D].
+ * ws f32 workspace of neat_loss_ws_floats(B,Bl) floats. */
+long neat_loss_ws_floats(int B, int Bl);
+int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const float* inv, const float* text_all,
+                          const float* coarse_all, float T1, float T2, float* losses, float* dtext,
+                          float* dpos, float* dinv, float* ws, int B, int Bl, int row0, int D,
+                          void* stream);
+
+/* ---- AdamW, torch.optim.AdamW(main_TTA.py:271) single-tensor update rule on a flat buffer ---- */
+int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                    float beta2, float eps, float wd, int step, void* stream);
+
+/* ---- retrieval scoring, evaluation/retrieval.py:280-301 ---- */
+/* Row-wise top-k of a strided f32 matrix (element (r,c) at scores[r*ld_row + c*ld_col]; one of the
+ * strides must be 1 -> accepts scores and scores.T).  idx i32 [R,k] descending, ties -> lowest index;
+ * val f32 [R,k] (may be NULL).  k <= 32.  ws: neat_topk_ws_bytes(R,Ncol,k) bytes. */
+long neat_topk_ws_bytes(int R, int Ncol, int k);
+int neat_topk_rows(const float* scores, long ld_row, long ld_col, int R, int Ncol, int k, int32_t* idx,
+                   float* val, void* ws, void* stream);
+/* recall[r] = |topk(r) ∩ positives(r)| / |positives(r)| with positives a strided uint8/bool matrix */
+int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, long ld_row, long ld_col, int R,
+                          int Ncol, int k, float* recall, void* stream);
+/* fp32 similarity GEMM C[M,N] = A[M,K] B[N,K]^T (exact fp32 FMA chain; feeds argmax/top-k) */
+int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+
+/* f32 -> bf16 cast (weights at load time, n elements) */
+int neat_cast_bf16(const float* src, uint16_t* dst, long n, void* stream);
+/* f32 [R,C] -> bf16 [C,R] transpose-cast (dgrad uses W^T stored K-contiguous) */
+int neat_transpose_cast_bf16(const float* src, uint16_t* dst, int R, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEAT_HIP_H */

@@ -1,0 +1,402 @@
+// Fused attention forward / backward for short sequences (text L = 77 causal; vision L = 50..257).
+// Replaces the SDPA core of nn.MultiheadAttention (reference open_clip/transformer.py:202,227-229,
+// causal mask :655-661) and its autograd backward.  head_dim is 64 for every CLIP ViT config.
+//
+// One 64-lane wavefront owns one (sequence, head); the whole score matrix of a head lives in MFMA
+// accumulators (L <= 272), so there is no online-softmax rescaling and no HBM round trip for S/P.
+//
+// Orientation trick (guide §3 "accumulator tile as the next MFMA's operand"): scores are computed
+// TRANSPOSED, S^T = K.Q^T, so the accumulator of v_mfma_f32_16x16x32_bf16 holds for one query
+// (= lane&15) four consecutive keys per register quad.  Softmax statistics are then lane-local plus two
+// xor-shuffles, and the bf16-packed accumulator is directly the B operand of the next product
+// (O^T = V^T.P^T, dQ^T = K^T.dS^T) with a permuted k order; the other operand is read with that same
+// k order from a [d][key] LDS image.  Products that sum over queries (dV, dK) use the second
+// orientation S = Q.K^T, recomputed from the saved log-sum-exp.
+#include "common.h"
+
+namespace neat {
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_WAVES = 4;
+constexpr int HD = 64;
+
+// 16-B fragment load of 8 consecutive head-dim elements of row `row` (clamped to < L)
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, long ld, int row, int L, int dofs) {
+    row = row < L ? row : L - 1;
+    return *reinterpret_cast<const bf16x8*>(base + (long)row * ld + dofs);
+}
+
+// stage X^T into LDS: T[d][key] (row pitch ldt elements), zero for key >= L
+__device__ __forceinline__ void stage_transposed(const bf16_t* base, long ld, int L, int LP, bf16_t* T, int ldt,
+                                                 int lane) {
+    for (int idx = lane; idx < LP * 8; idx += 64) {
+        const int key = idx >> 3, ch = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < L) v = *reinterpret_cast<const uint4*>(base + (long)key * ld + ch * 8);
+        bf16_t* dst = T + (ch * 8) * ldt + key;
+        dst[0 * ldt] = (bf16_t)(v.x & 0xffff); dst[1 * ldt] = (bf16_t)(v.x >> 16);
+        dst[2 * ldt] = (bf16_t)(v.y & 0xffff); dst[3 * ldt] = (bf16_t)(v.y >> 16);
+        dst[4 * ldt] = (bf16_t)(v.z & 0xffff); dst[5 * ldt] = (bf16_t)(v.z >> 16);
+        dst[6 * ldt] = (bf16_t)(v.w & 0xffff); dst[7 * ldt] = (bf16_t)(v.w >> 16);
+    }
+}
+
+// A-operand fragment of T (rows = d) for the k-step that covers 16-wide tiles ta and tb of the summed
+// index: elements 0..3 <- T[d][ta*16 + 4*fq + 0..3], 4..7 <- T[d][tb*16 + 4*fq + 0..3]
+__device__ __forceinline__ bf16x8 tfrag(const bf16_t* T, int ldt, int d, int ta, int tb, int fq) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(T + d * ldt + ta * 16 + fq * 4);
+    const uint2 hi = *reinterpret_cast<const uint2*>(T + d * ldt + tb * 16 + fq * 4);
+    uint4 r = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ bf16x8 pack_acc2(const f32x4& a, const f32x4& b) {
+    uint4 r = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ float xor_max_16_32(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum_16_32(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+template <int NT>
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+                                                              bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                              int nseq, int L, int heads, int causal) {
+    constexpr int LP = NT * 16;
+    constexpr int LDT = LP + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int C = heads * HD;
+    const long ld = 3L * C;
+    const int total = nseq * heads;
+    int item = blockIdx.x * AT_WAVES + wave;
+    const bool live = item < total;
+    if (!live) item = total - 1;
+    const int s = item / heads, h = item - s * heads;
+    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
+    const bf16_t* kb = qb + C;
+    const bf16_t* vb = qb + 2 * C;
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem) + (long)wave * HD * LDT;
+    stage_transposed(vb, ld, L, LP, Vt, LDT, lane);
+    __syncthreads();
+    const float scale = 0.125f;  // 1/sqrt(64)
+
+    for (int qt = 0; qt < NT; ++qt) {
+        const int q0 = qt * 16;
+        if (q0 >= L) break;
+        const int query = q0 + fr;
+        const bf16x8 qf0 = gfrag(qb, ld, query, L, fq * 8);
+        const bf16x8 qf1 = gfrag(qb, ld, query, L, 32 + fq * 8);
+        const int nkt = causal ? qt + 1 : NT;
+        f32x4 st[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                const bf16x8 kf0 = gfrag(kb, ld, kt * 16 + fr, L, fq * 8);
+                const bf16x8 kf1 = gfrag(kb, ld, kt * 16 + fr, L, 32 + fq * 8);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, st[kt], 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, st[kt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fq * 4 + r;
+                const bool ok = kt < nkt && key < L && (!causal || key <= query);
+                st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        }
+        mx = xor_max_16_32(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[kt][r] = __expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
+                sum += st[kt][r];
+            }
+        sum = xor_sum_16_32(sum);
+        if (lse && live && fq == 0 && query < L) lse[((long)s * heads + h) * L + query] = mx + __logf(sum);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < (NT + 1) / 2; ++ks) {
+            if (2 * ks < nkt) {
+                const int ta = 2 * ks, tb = (2 * ks + 1 < NT) ? 2 * ks + 1 : 2 * ks;
+                f32x4 hi = (2 * ks + 1 < NT) ? st[tb] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x8 pf = pack_acc2(st[ta], hi);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vf = tfrag(Vt, LDT, dt * 16 + fr, ta, tb, fq);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (live && query < L) {
+            const float inv = 1.0f / sum;
+            bf16_t* orow = out + ((long)s * L + query) * C + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(orow + dt * 16 + fq * 4) =
+                    make_uint2(pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv));
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv,
+                                                              const bf16_t* __restrict__ dout,
+                                                              const float* __restrict__ lse,
+                                                              bf16_t* __restrict__ dqkv, int nseq, int L, int heads,
+                                                              int causal) {
+    constexpr int LP = NT * 16;
+    constexpr int LDT = LP + 8;
+    constexpr int NP = (NT + 1) / 2;  // pairs of 16-wide tiles = MFMA k-steps over a summed sequence index
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int C = heads * HD;
+    const long ld = 3L * C;
+    const int total = nseq * heads;
+    int item = blockIdx.x * AT_WAVES + wave;
+    const bool live = item < total;
+    if (!live) item = total - 1;
+    const int s = item / heads, h = item - s * heads;
+    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
+    const bf16_t* kb = qb + C;
+    const bf16_t* vb = qb + 2 * C;
+    const bf16_t* dob = dout + (long)s * L * C + h * HD;
+    const float* lser = lse + ((long)s * heads + h) * L;
+    bf16_t* dqb = dqkv + (long)s * L * ld + h * HD;
+    bf16_t* dkb = dqb + C;
+    bf16_t* dvb = dqb + 2 * C;
+
+    char* wbase = smem + (long)wave * (3 * HD * LDT * 2 + LP * 4);
+    bf16_t* Kt = reinterpret_cast<bf16_t*>(wbase);
+    bf16_t* Qt = Kt + HD * LDT;
+    bf16_t* dOt = Qt + HD * LDT;
+    float* delta = reinterpret_cast<float*>(dOt + HD * LDT);
+    stage_transposed(kb, ld, L, LP, Kt, LDT, lane);
+    stage_transposed(qb, ld, L, LP, Qt, LDT, lane);
+    stage_transposed(dob, C, L, LP, dOt, LDT, lane);
+    __syncthreads();
+    const float scale = 0.125f;
+
+    // ---- pass 1: per query tile in the S^T orientation (query on the lane) -> delta, dQ ----
+    for (int qt = 0; qt < NT; ++qt) {
+        const int q0 = qt * 16;
+        const int query = q0 + fr;
+        const int nkt = causal ? qt + 1 : NT;
+        const bf16x8 qf0 = gfrag(qb, ld, query, L, fq * 8), qf1 = gfrag(qb, ld, query, L, 32 + fq * 8);
+        const bf16x8 df0 = gfrag(dob, C, query, L, fq * 8), df1 = gfrag(dob, C, query, L, 32 + fq * 8);
+        const float lq = lser[query < L ? query : L - 1];
+        f32x4 pv[NT], ds[NT];
+        float dl = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                const int krow = kt * 16 + fr;
+                const bf16x8 kf0 = gfrag(kb, ld, krow, L, fq * 8), kf1 = gfrag(kb, ld, krow, L, 32 + fq * 8);
+                const bf16x8 vf0 = gfrag(vb, ld, krow, L, fq * 8), vf1 = gfrag(vb, ld, krow, L, 32 + fq * 8);
+                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, sv, 0, 0, 0);
+                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, sv, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, df0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, df1, dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fq * 4 + r;
+                const bool ok = kt < nkt && key < L && query < L && (!causal || key <= query);
+                const float p = ok ? __expf(sv[r] * scale - lq) : 0.f;
+                pv[kt][r] = p;
+                ds[kt][r] = dp[r];
+                dl += p * dp[r];
+            }
+        }
+        dl = xor_sum_16_32(dl);  // delta[query] = sum_key P * dP  (= rowsum(dO * O))
+        if (fq == 0) delta[q0 + fr] = dl;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kt][r] = pv[kt][r] * (ds[kt][r] - dl) * scale;
+        // dQ^T[d, query] = sum_key K^T[d,key] dS^T[key,query]
+        f32x4 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NP; ++ks) {
+            if (2 * ks < nkt) {
+                const int ta = 2 * ks, tb = (2 * ks + 1 < NT) ? 2 * ks + 1 : 2 * ks;
+                const f32x4 hi = (2 * ks + 1 < NT) ? ds[tb] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x8 sf = pack_acc2(ds[ta], hi);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 kf = tfrag(Kt, LDT, dt * 16 + fr, ta, tb, fq);
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, acc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (live && query < L) {
+            bf16_t* row = dqb + (long)query * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(row + dt * 16 + fq * 4) =
+                    make_uint2(pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3]));
+        }
+    }
+    __syncthreads();  // delta[] complete (same wave wrote it; barrier also orders the LDS accesses)
+
+    // ---- pass 2: per key tile in the S orientation (key on the lane) -> dV, dK ----
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k0 = kt * 16;
+        if (k0 >= L) break;
+        const int key = k0 + fr;
+        const bf16x8 kf0 = gfrag(kb, ld, key, L, fq * 8), kf1 = gfrag(kb, ld, key, L, 32 + fq * 8);
+        const bf16x8 vf0 = gfrag(vb, ld, key, L, fq * 8), vf1 = gfrag(vb, ld, key, L, 32 + fq * 8);
+        f32x4 av[4], ak[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            av[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int qp0 = causal ? (kt >> 1) : 0;  // first pair of query tiles that can see this key tile
+#pragma unroll
+        for (int qp = 0; qp < NP; ++qp) {
+            if (qp < qp0) continue;
+            f32x4 pt[2], dt2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int qt = 2 * qp + e;
+                pt[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dt2[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool tile_ok = qt < NT && qt * 16 < L && (!causal || qt >= kt);
+                if (tile_ok) {
+                    const int qrow = qt * 16 + fr;
+                    const bf16x8 qf0 = gfrag(qb, ld, qrow, L, fq * 8), qf1 = gfrag(qb, ld, qrow, L, 32 + fq * 8);
+                    const bf16x8 df0 = gfrag(dob, C, qrow, L, fq * 8), df1 = gfrag(dob, C, qrow, L, 32 + fq * 8);
+                    f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // D[query][key]: A = Q rows (queries), B = K rows as columns (keys)
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0, kf0, sv, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, kf1, sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df0, vf0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df1, vf1, dp, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int query = qt * 16 + fq * 4 + r;
+                        const bool ok = key < L && query < L && (!causal || key <= query);
+                        const int qc = query < L ? query : L - 1;
+                        const float p = ok ? __expf(sv[r] * scale - lser[qc]) : 0.f;
+                        pt[e][r] = p;
+                        dt2[e][r] = p * (dp[r] - delta[query]) * scale;
+                    }
+                }
+            }
+            const int ta = 2 * qp, tb = (2 * qp + 1 < NT) ? 2 * qp + 1 : 2 * qp;
+            const bf16x8 pf = pack_acc2(pt[0], pt[1]);
+            const bf16x8 sf = pack_acc2(dt2[0], dt2[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 of = tfrag(dOt, LDT, dt * 16 + fr, ta, tb, fq);   // dO^T[d][query]
+                const bf16x8 qf = tfrag(Qt, LDT, dt * 16 + fr, ta, tb, fq);    // Q^T[d][query]
+                av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, pf, av[dt], 0, 0, 0);  // dV^T[d,key]
+                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[dt], 0, 0, 0);  // dK^T[d,key]
+            }
+        }
+        if (live && key < L) {
+            bf16_t* vrow = dvb + (long)key * ld;
+            bf16_t* krow = dkb + (long)key * ld;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<uint2*>(vrow + dt * 16 + fq * 4) =
+                    make_uint2(pack2bf(av[dt][0], av[dt][1]), pack2bf(av[dt][2], av[dt][3]));
+                *reinterpret_cast<uint2*>(krow + dt * 16 + fq * 4) =
+                    make_uint2(pack2bf(ak[dt][0], ak[dt][1]), pack2bf(ak[dt][2], ak[dt][3]));
+            }
+        }
+    }
+}
+
+static inline int attn_nt(int L) {
+    if (L <= 16) return 1;
+    if (L <= 64) return 4;
+    if (L <= 80) return 5;
+    if (L <= 208) return 13;
+    if (L <= 272) return 17;
+    return 0;
+}
+
+template <int NT>
+static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
+                      hipStream_t s) {
+    constexpr size_t lds = (size_t)AT_WAVES * HD * (NT * 16 + 8) * 2;
+    static bool attr = false;
+    if (!attr) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attn_fwd attr");
+        if (rc) return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(cdiv((long)nseq * heads, AT_WAVES)), dim3(AT_THREADS), lds, s, qkv,
+                       out, lse, nseq, L, heads, causal);
+    NEAT_LAUNCH_CHECK("neat_attn_fwd");
+    return NEAT_OK;
+}
+
+template <int NT>
+static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq, int L,
+                      int heads, int causal, hipStream_t s) {
+    constexpr size_t lds = (size_t)AT_WAVES * (3 * HD * (NT * 16 + 8) * 2 + NT * 16 * 4);
+    static bool attr = false;
+    if (!attr) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attn_bwd attr");
+        if (rc) return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(cdiv((long)nseq * heads, AT_WAVES)), dim3(AT_THREADS), lds, s, qkv,
+                       dout, lse, dqkv, nseq, L, heads, causal);
+    NEAT_LAUNCH_CHECK("neat_attn_bwd");
+    return NEAT_OK;
+}
+
+}  // namespace neat
+
+using namespace neat;
+
+extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
+                             void* stream) {
+    NEAT_REQUIRE(qkv && out, NEAT_ERR_ARG, "neat_attn_fwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    switch (attn_nt(L)) {
+        case 1: return launch_fwd<1>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 4: return launch_fwd<4>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 5: return launch_fwd<5>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 13: return launch_fwd<13>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 17: return launch_fwd<17>(qkv, out, lse, nseq, L, heads, causal, s);
+        default: return set_error(NEAT_ERR_SHAPE, "neat_attn_fwd: sequence length %d > 272 unsupported", L);
+    }
+}
+
+extern "C" int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq,
+                             int L, int heads, int causal, void* stream) {
+    NEAT_REQUIRE(qkv && dout && lse && dqkv, NEAT_ERR_ARG, "neat_attn_bwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    switch (attn_nt(L)) {
+        case 1: return launch_bwd<1>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
+        case 4: return launch_bwd<4>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
+        case 5: return launch_bwd<5>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
+        default: return set_error(NEAT_ERR_SHAPE, "neat_attn_bwd: sequence length %d > 80 unsupported", L);
+    }
+}

@@ -1,0 +1,68 @@
+// Shared device/host helpers for libneat_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/neat_hip.h"
+
+namespace neat {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16; NaN stays NaN (a plain cast lowers to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// QuickGELU, reference open_clip/transformer.py:33-36
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    float s = sigmoidf_(1.702f * x);
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+// ---- error plumbing (capi.hip) ----
+int set_error(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define NEAT_REQUIRE(cond, code, ...) \
+    do {                              \
+        if (!(cond)) return ::neat::set_error((code), __VA_ARGS__); \
+    } while (0)
+
+#define NEAT_LAUNCH_CHECK(what) \
+    do {                         \
+        int _rc = ::neat::check_hip(hipGetLastError(), (what)); \
+        if (_rc) return _rc;     \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace neat

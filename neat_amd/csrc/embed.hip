@@ -1,0 +1,334 @@
+// Small HBM-bound kernels around the encoders: token embedding, EOT argmax, pooled head
+// (final LayerNorm + projection + L2-normalise) forward/backward, ViT stem helpers, casts.
+#include "common.h"
+
+namespace neat {
+
+// ---- nn.Embedding + positional add (reference open_clip/model.py:272-274) ----
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                 const float* __restrict__ pos_emb, float* __restrict__ x, long rows, int L, int C,
+                                 int vocab) {
+    const int c4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c4;
+        const int c = (int)(i - row * c4);
+        long id = tokens[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float4 a = reinterpret_cast<const float4*>(tok_emb + id * C)[c];
+        const float4 p = reinterpret_cast<const float4*>(pos_emb + (row % L) * C)[c];
+        reinterpret_cast<float4*>(x + row * C)[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+// ---- text.argmax(dim=-1) (reference open_clip/transformer.py:555-558); first maximum wins ----
+__global__ void eot_index_kernel(const int64_t* __restrict__ tokens, int32_t* __restrict__ eot, int nseq, int L) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseq) return;
+    const int64_t* t = tokens + (long)s * L;
+    int64_t best = t[0];
+    int bi = 0;
+    for (int l = 1; l < L; ++l)
+        if (t[l] > best) { best = t[l]; bi = l; }
+    eot[s] = bi;
+}
+
+// ---- pooled head forward: one block per sequence ----
+// pooled row -> LayerNorm (fp32) -> @ proj [C,D] -> optional F.normalize
+// (reference open_clip/model.py:278-286, open_clip/transformer.py:538-542, model.py:267)
+constexpr int PP_THREADS = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void pool_proj_fwd_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ proj, float* __restrict__ feat, float* __restrict__ xe,
+    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ nrm, int L, int C, int D, int normalize,
+    float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* z = sm;            // [C]
+    float* f = sm + C;        // [D]
+    float* red = f + D;       // [8]
+    const int s = blockIdx.x;
+    const long row = (long)s * L + (row_idx ? row_idx[s] : 0);
+    const float* xr = x + row * C;
+    float a = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v = xr[c];
+        z[c] = v;
+        if (xe) xe[(long)s * C + c] = v;
+        a += v;
+    }
+    const float mu = block_sum(a, red) / C;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float d = z[c] - mu;
+        q += d * d;
+    }
+    const float rs = rsqrtf(block_sum(q, red) / C + eps);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) z[c] = (z[c] - mu) * rs * gamma[c] + beta[c];
+    __syncthreads();
+    float n2 = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(z[c], proj[(long)c * D + d], acc);
+        f[d] = acc;
+        n2 += acc * acc;
+    }
+    const float nr = sqrtf(block_sum(n2, red));
+    const float inv = normalize ? 1.0f / fmaxf(nr, 1e-12f) : 1.0f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) feat[(long)s * D + d] = f[d] * inv;
+    if (threadIdx.x == 0) {
+        if (mean) mean[s] = mu;
+        if (rstd) rstd[s] = rs;
+        if (nrm) nrm[s] = nr;
+    }
+}
+
+// backward: dfeat -> (normalize bwd) -> @ proj^T -> LN backward (data grad only) -> scatter to pooled row
+__global__ __launch_bounds__(PP_THREADS) void pool_proj_bwd_kernel(
+    const float* __restrict__ dfeat, const float* __restrict__ feat, const float* __restrict__ nrm,
+    const float* __restrict__ xe, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ proj, const int32_t* __restrict__ row_idx,
+    float* __restrict__ dxf, bf16_t* __restrict__ dxb, int L, int C, int D, int normalize) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* df = sm;           // [D]
+    float* g = sm + D;        // [C]
+    float* red = g + C;       // [8]
+    const int s = blockIdx.x;
+    float dot = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float v = dfeat[(long)s * D + d];
+        df[d] = v;
+        if (normalize) dot += v * feat[(long)s * D + d];
+    }
+    if (normalize) {
+        dot = block_sum(dot, red);
+        const float inv = 1.0f / fmaxf(nrm[s], 1e-12f);
+        for (int d = threadIdx.x; d < D; d += blockDim.x) df[d] = (df[d] - feat[(long)s * D + d] * dot) * inv;
+    }
+    __syncthreads();
+    const float mu = mean[s], rs = rstd[s];
+    // dz = df @ proj^T; one wave per output column c, lanes stride d
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int c = wave; c < C; c += nw) {
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc = fmaf(df[d], proj[(long)c * D + d], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) g[c] = acc * gamma[c];
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float xh = (xe[(long)s * C + c] - mu) * rs;
+        s1 += g[c];
+        s2 += g[c] * xh;
+    }
+    s1 = block_sum(s1, red) / C;
+    s2 = block_sum(s2, red) / C;
+    const long row = (long)s * L + (row_idx ? row_idx[s] : 0);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float xh = (xe[(long)s * C + c] - mu) * rs;
+        const float o = rs * (g[c] - s1 - xh * s2);
+        if (dxf) dxf[row * C + c] = o;
+        if (dxb) dxb[row * C + c] = f2bf(o);
+    }
+}
+
+// ---- ViT stem ----
+// images f32 NCHW -> bf16 patch matrix [n*gh*gw, Kpad], column order (c, kh, kw) = conv1.weight.view(width,-1)
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n, int H, int W, int patch,
+                                int Kpad) {
+    const int gh = H / patch, gw = W / patch;
+    const int K = 3 * patch * patch;
+    const long total = (long)n * gh * gw * Kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const long prow = i / Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int kw = k % patch, kh = (k / patch) % patch, c = k / (patch * patch);
+            const int pw = (int)(prow % gw), ph = (int)((prow / gw) % gh);
+            const long b = prow / ((long)gw * gh);
+            v = img[((b * 3 + c) * H + ph * patch + kh) * (long)W + pw * patch + kw];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+// x[b,0] = cls + pos[0]; x[b,1+p] = patch_emb[b,p] + pos[1+p]; then ln_pre.  One wave per token row.
+__global__ __launch_bounds__(256) void vision_embed_kernel(const float* __restrict__ patch_emb,
+                                                           const float* __restrict__ cls,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ x,
+                                                           long rows, int P, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = P + 1;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const long b = row / T;
+        const int t = (int)(row - b * T);
+        const float* src = t == 0 ? cls : patch_emb + (b * P + (t - 1)) * (long)C;
+        const float* pr = pos + (long)t * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += src[c] + pr[c];
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = src[c] + pr[c] - mu;
+            q += d * d;
+        }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+        for (int c = lane; c < C; c += 64) x[row * C + c] = (src[c] + pr[c] - mu) * rs * gamma[c] + beta[c];
+    }
+}
+
+// VideoCLIP pooling (reference utils/video_utils/model.py:62-74,90-91): mean over frames, re-normalise
+__global__ void frame_mean_norm_kernel(const float* __restrict__ feat, float* __restrict__ out, int F, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* red = sm + D;
+    const int v = blockIdx.x;
+    float n2 = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float a = 0.f;
+        for (int f = 0; f < F; ++f) a += feat[((long)v * F + f) * D + d];
+        a /= F;
+        sm[d] = a;
+        n2 += a * a;
+    }
+    const float nr = sqrtf(block_sum(n2, red));
+    const float inv = 1.0f / fmaxf(nr, 1e-12f);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[(long)v * D + d] = sm[d] * inv;
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = f2bf(src[i]);
+}
+
+// src f32 [R,C] -> dst bf16 [C,R]; 32x32 LDS tile
+__global__ void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < C) dst[(long)c * R + r] = f2bf(tile[threadIdx.x][j]);
+    }
+}
+
+static inline int ew_grid(long n, int threads) {
+    long g = (n + threads - 1) / threads;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace neat
+
+using namespace neat;
+
+extern "C" int neat_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* x, int nseq,
+                              int L, int C, int vocab, void* stream) {
+    NEAT_REQUIRE(tokens && tok_emb && pos_emb && x, NEAT_ERR_ARG, "neat_embed_fwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && C % 4 == 0 && vocab > 0, NEAT_ERR_SHAPE, "neat_embed_fwd: bad shape");
+    const long rows = (long)nseq * L;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, tokens,
+                       tok_emb, pos_emb, x, rows, L, C, vocab);
+    NEAT_LAUNCH_CHECK("neat_embed_fwd");
+    return NEAT_OK;
+}
+
+extern "C" int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int L, void* stream) {
+    NEAT_REQUIRE(tokens && eot, NEAT_ERR_ARG, "neat_eot_index: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0, NEAT_ERR_SHAPE, "neat_eot_index: bad shape");
+    hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(nseq, 128)), dim3(128), 0, (hipStream_t)stream, tokens, eot, nseq, L);
+    NEAT_LAUNCH_CHECK("neat_eot_index");
+    return NEAT_OK;
+}
+
+extern "C" int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,
+                                  const float* proj, float* feat, float* xe, float* mean, float* rstd, float* nrm,
+                                  int nseq, int L, int C, int D, int normalize, float eps, void* stream) {
+    NEAT_REQUIRE(x && gamma && beta && proj && feat, NEAT_ERR_ARG, "neat_pool_proj_fwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000, NEAT_ERR_SHAPE,
+                 "neat_pool_proj_fwd: bad shape C=%d D=%d", C, D);
+    hipLaunchKernelGGL(pool_proj_fwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
+                       x, row_idx, gamma, beta, proj, feat, xe, mean, rstd, nrm, L, C, D, normalize, eps);
+    NEAT_LAUNCH_CHECK("neat_pool_proj_fwd");
+    return NEAT_OK;
+}
+
+extern "C" int neat_pool_proj_bwd(const float* dfeat, const float* feat, const float* nrm, const float* xe,
+                                  const float* mean, const float* rstd, const float* gamma, const float* proj,
+                                  const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, int nseq, int L, int C,
+                                  int D, int normalize, void* stream) {
+    NEAT_REQUIRE(dfeat && xe && mean && rstd && gamma && proj && (dx_f32 || dx_bf16), NEAT_ERR_ARG,
+                 "neat_pool_proj_bwd: null pointer");
+    NEAT_REQUIRE(!normalize || (feat && nrm), NEAT_ERR_ARG, "neat_pool_proj_bwd: normalize needs feat, nrm");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000, NEAT_ERR_SHAPE,
+                 "neat_pool_proj_bwd: bad shape");
+    hipLaunchKernelGGL(pool_proj_bwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
+                       dfeat, feat, nrm, xe, mean, rstd, gamma, proj, row_idx, dx_f32, dx_bf16, L, C, D, normalize);
+    NEAT_LAUNCH_CHECK("neat_pool_proj_bwd");
+    return NEAT_OK;
+}
+
+extern "C" int neat_patchify(const float* images, uint16_t* patches, int n, int H, int W, int patch, int Kpad,
+                             void* stream) {
+    NEAT_REQUIRE(images && patches, NEAT_ERR_ARG, "neat_patchify: null pointer");
+    NEAT_REQUIRE(n > 0 && patch > 0 && H % patch == 0 && W % patch == 0 && Kpad >= 3 * patch * patch, NEAT_ERR_SHAPE,
+                 "neat_patchify: bad shape");
+    const long total = (long)n * (H / patch) * (W / patch) * Kpad;
+    hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, images, patches, n,
+                       H, W, patch, Kpad);
+    NEAT_LAUNCH_CHECK("neat_patchify");
+    return NEAT_OK;
+}
+
+extern "C" int neat_vision_embed(const float* patch_emb, const float* cls, const float* pos, const float* gamma,
+                                 const float* beta, float* x, int n, int P, int C, float eps, void* stream) {
+    NEAT_REQUIRE(patch_emb && cls && pos && gamma && beta && x, NEAT_ERR_ARG, "neat_vision_embed: null pointer");
+    NEAT_REQUIRE(n > 0 && P > 0 && C > 0, NEAT_ERR_SHAPE, "neat_vision_embed: bad shape");
+    const long rows = (long)n * (P + 1);
+    hipLaunchKernelGGL(vision_embed_kernel, dim3(ew_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, patch_emb, cls,
+                       pos, gamma, beta, x, rows, P, C, eps);
+    NEAT_LAUNCH_CHECK("neat_vision_embed");
+    return NEAT_OK;
+}
+
+extern "C" int neat_frame_mean_norm(const float* feat, float* out, int n, int F, int D, void* stream) {
+    NEAT_REQUIRE(feat && out, NEAT_ERR_ARG, "neat_frame_mean_norm: null pointer");
+    NEAT_REQUIRE(n > 0 && F > 0 && D > 0 && D <= 8192, NEAT_ERR_SHAPE, "neat_frame_mean_norm: bad shape");
+    hipLaunchKernelGGL(frame_mean_norm_kernel, dim3(n), dim3(256), (size_t)(D + 8) * 4, (hipStream_t)stream, feat, out, F,
+                       D);
+    NEAT_LAUNCH_CHECK("neat_frame_mean_norm");
+    return NEAT_OK;
+}
+
+extern "C" int neat_cast_bf16(const float* src, uint16_t* dst, long n, void* stream) {
+    NEAT_REQUIRE(src && dst, NEAT_ERR_ARG, "neat_cast_bf16: null pointer");
+    if (n <= 0) return NEAT_OK;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    NEAT_LAUNCH_CHECK("neat_cast_bf16");
+    return NEAT_OK;
+}
+
+extern "C" int neat_transpose_cast_bf16(const float* src, uint16_t* dst, int R, int C, void* stream) {
+    NEAT_REQUIRE(src && dst, NEAT_ERR_ARG, "neat_transpose_cast_bf16: null pointer");
+    NEAT_REQUIRE(R > 0 && C > 0, NEAT_ERR_SHAPE, "neat_transpose_cast_bf16: bad shape");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src,
+                       dst, R, C);
+    NEAT_LAUNCH_CHECK("neat_transpose_cast_bf16");
+    return NEAT_OK;
+}
