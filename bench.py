@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the NEAT test-time-adaptation hot path on MI355X.
+
+Metric (BASELINE.json): TTA image-text pairs/sec, ViT-B/32, batch 256, 3 steps.
+A "step" of this harness = one adaptation batch: 4 text-tower forwards + coarse alignment + loss/grad +
+3 text-tower backwards + AdamW, repeated tta_steps=3 times, and the batch's score rows written
+(reference train_TTA.py:125-150).  value = caption rows fully adapted per second, whole job.
+
+Workload at N=1: BASELINE config 2 -- CLIP ViT-B-32, gallery of 5 000 images, batches of 256 caption
+rows (text/pos/neg/inv token sets), synthetic tokens/images of NegBench-COCO shape, random-init weights of
+the ViT-B-32 architecture.  Inputs are resident in HBM when the timed region starts.  The gallery encode
+(Phase A, once per epoch) is timed separately and reported as ``gallery_images_per_s``.
+
+N>1 (launched by torch.distributed.run): weak scaling -- every rank owns 256 rows of a global batch of
+256*N (BASELINE config 3's sharding); features are all-gathered and LN gradients all-reduced over RCCL.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (bf16 MFMA GEMM, timed with HIP events
+on its stream inside the timed region) and ``cpu_baseline`` (the CPU oracle on a bounded sample of the same
+workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6, help="timed adaptation batches")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="ViT-B-32")
+    ap.add_argument("--batch", type=int, default=256, help="caption rows per GPU per batch")
+    ap.add_argument("--gallery", type=int, default=5000)
+    ap.add_argument("--tta-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="caption rows in the CPU-oracle sample")
+    return ap.parse_args()
+
+
+def text_tower_flops_per_row_step(cfg, L):
+    """Algorithmic FLOPs per caption row per TTA step: 4 fwd + 3 bwd (dgrad only)."""
+    t = cfg["text_cfg"]
+    C, layers = t["width"], t["layers"]
+    lin = 12 * C * C            # MACs per token per layer: qkv 3C^2 + out C^2 + mlp 8C^2
+    att = 2 * L * C             # QK^T and PV, dense
+    fwd = 2.0 * L * layers * (lin + att)
+    bwd = 2.0 * L * layers * (lin + 2.5 * att)
+    return 4 * fwd + 3 * bwd
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from neat_amd import lib, open_clip as oc, ops, synth
+    from neat_amd import train_TTA as T
+    from neat_amd.optim import AdamW
+    lib.load()
+
+    cfg = synth.get_cfg(a.model)
+    tcfg = cfg["text_cfg"]
+    L = tcfg["context_length"]
+    model = oc.create_model(a.model, device=dev)
+    model.load_state_dict(synth.synth_state_dict(a.model, 0))
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+
+    # ---- Phase A: gallery (timed separately; each rank encodes its shard, then all-gather) ----
+    n_img = a.gallery
+    lo, hi = T._shard(n_img, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    G_local = torch.empty(hi - lo, cfg["embed_dim"], device=dev)
+    isz = cfg["vision_cfg"]["image_size"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for s in range(0, hi - lo, 250):
+            e = min(hi - lo, s + 250)
+            img = torch.randn(e - s, 3, isz, isz, generator=g, device=dev)
+            G_local[s:e] = model.encode_image(img, normalize=True)
+    torch.cuda.synchronize()
+    gallery_s = time.perf_counter() - t0
+    G = T._all_gather_rows(G_local, n_img, world) if world > 1 else G_local
+    del img
+
+    # ---- synthetic caption batches, resident in HBM ----
+    nb = a.steps + a.warmup
+    B = a.batch
+    batches = []
+    for i in range(nb):
+        sets = synth.synth_caption_sets(B, L, tcfg["vocab_size"], 1000 + 7919 * rank + i)
+        batches.append([s.to(dev) for s in sets])
+    n_text = B * world * nb
+    score = torch.full((B * nb, n_img), -100.0, device=dev)      # this rank's score rows
+
+    timer = ops.KernelTimer(lib.EPI_BIAS_GELU)       # c_fc GEMM: largest single GEMM of the step
+    ops.KERNEL_TIMER = timer
+
+    def run_batch(i):
+        for _ in range(a.tta_steps):
+            losses, idx, S = T.tta_step(model, opt, batches[i], G, 0.03, 0.07, world, rank)
+        score[i * B:(i + 1) * B] = S
+        return losses
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        run_batch(i)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(a.warmup, nb):
+        losses = run_batch(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    pairs = a.steps * B * world
+    value = pairs / dt
+
+    # ---- roofline of the dominant kernel (events recorded inside the timed region) ----
+    avg_ms, avg_flop, nl = timer.summary()
+    achieved = avg_flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    flops_row_step = text_tower_flops_per_row_step(cfg, L)
+    roofline = dict(bound="mfma", kernel="gemm_bf16_kernel<NEAT_EPI_BIAS_GELU> (c_fc, M=4*B*77, N=4C, K=C)",
+                    achieved=round(achieved, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches=nl,
+                    avg_launch_ms=round(avg_ms, 4),
+                    step_tflops=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12, 1))
+
+    # recall@1 on the produced score rows (synthetic ground truth: caption r <-> image r % N)
+    from neat_amd.evaluation import retrieval as R
+    rows = torch.arange(B * nb, device=dev)
+    pos = torch.zeros_like(score, dtype=torch.bool)
+    pos[rows, rows % n_img] = True
+    r1 = (R.recall_at_k(score, pos, 1) > 0).float().mean().item()
+
+    out = dict(metric="TTA image-text pairs/sec (ViT-B/32, bs256, 3 steps)", value=round(value, 2), unit="pairs/s",
+               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+               config=dict(workload=f"BASELINE config 2: CLIP {a.model} NEAT t2i TTA, gallery {n_img} images, "
+                                    f"batches of {B} caption rows per GPU x {a.tta_steps} steps, L={L}",
+                           global_batch=B * world, tta_steps=a.tta_steps, gallery=n_img,
+                           parallelism=f"dp{world}"),
+               gallery_images_per_s=round(n_img / gallery_s / 1.0, 1), recall_at_1_t2i=r1,
+               last_losses=[round(x, 4) for x in losses.tolist()], roofline=roofline)
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, cfg)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, cfg):
+    """The CPU oracle (plain-PyTorch fp32 restatement of the reference loop, oracle/neat_oracle.py) on a
+    bounded sample of the same workload: one batch of --cpu-sample caption rows x tta_steps, gallery of 64
+    (gallery encode excluded, as in the GPU number)."""
+    from neat_amd import synth
+    from oracle import neat_oracle as O
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(a.model, 0)
+    t = cfg["text_cfg"]
+    Bc = a.cpu_sample
+    toks = synth.synth_caption_sets(Bc, t["context_length"], t["vocab_size"], 1000)
+    G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"]), dim=-1)
+    st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
+    t0 = time.perf_counter()
+    for _ in range(a.tta_steps):
+        O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)
+    dt = time.perf_counter() - t0
+    return dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, kind="port",
+                sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, {a.model}, fp32 torch CPU oracle, "
+                       f"{dt:.1f} s")
+
+
+if __name__ == "__main__":
+    main()

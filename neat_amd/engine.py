@@ -1,0 +1,150 @@
+"""Encoder towers on HIP kernels: frozen weights in kernel layout, forward with saved activations and
+the hand-written backward that yields the LayerNorm gamma/beta gradients.
+
+Data layout in HBM (row-major, rows = tokens of all sequences back to back):
+  residual stream x        fp32 [M, C]      one buffer per LayerNorm input (saved for backward)
+  LN output / attn output  bf16 [M, C]      GEMM A operands (temporaries)
+  qkv                      bf16 [M, 3C]     saved per layer (attention backward recomputes P from lse)
+  MLP pre-activation h     bf16 [M, 4C]     saved per layer (QuickGELU')
+  weights                  bf16 [N, K] K-contiguous, plus the transposed copy [K, N] for the
+                           data-gradient GEMMs (weights are frozen: no wgrad, copies made once)
+  LN gamma/beta, biases, statistics, features, loss, optimizer state: fp32.
+
+Reference call sites: open_clip/model.py:265-286 (encode_image / encode_text),
+open_clip/transformer.py:188-243 (ResidualAttentionBlock), :502-547 (VisionTransformer.forward).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib, ops
+
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+class BlockWeights:
+    """One ResidualAttentionBlock in kernel layout.  ln_* are the LIVE fp32 parameter tensors."""
+
+    def __init__(self, blk, need_bwd: bool):
+        self.ln1_w, self.ln1_b = blk.ln_1.weight, blk.ln_1.bias
+        self.ln2_w, self.ln2_b = blk.ln_2.weight, blk.ln_2.bias
+        mats = dict(qkv=blk.attn.in_proj_weight, o=blk.attn.out_proj.weight, fc=blk.mlp.c_fc.weight,
+                    proj=blk.mlp.c_proj.weight)
+        self.w = {k: ops.cast_bf16(v.detach().contiguous()) for k, v in mats.items()}
+        self.wT = {k: ops.transpose_cast_bf16(v.detach().contiguous()) for k, v in mats.items()} if need_bwd else None
+        self.b = dict(qkv=blk.attn.in_proj_bias.detach(), o=blk.attn.out_proj.bias.detach(),
+                      fc=blk.mlp.c_fc.bias.detach(), proj=blk.mlp.c_proj.bias.detach())
+
+
+class Stack:
+    """Transformer stack (open_clip/transformer.py:291-325) on HIP kernels."""
+
+    def __init__(self, transformer, heads: int, causal: bool, need_bwd: bool):
+        self.blocks = [BlockWeights(b, need_bwd) for b in transformer.resblocks]
+        self.heads, self.causal = heads, causal
+
+    def forward(self, x, nseq: int, L: int, save: Optional[list]):
+        """x fp32 [nseq*L, C] -> fp32 [nseq*L, C].  With ``save`` a list, per-layer tensors needed by
+        ``backward`` are appended (and x buffers are never overwritten)."""
+        for w in self.blocks:
+            y, _, mu1, rs1 = ops.ln_fwd(x, w.ln1_w, w.ln1_b, save_stats=save is not None)
+            qkv, _ = ops.gemm(y, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
+            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None)
+            x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
+            y, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=save is not None)
+            h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"])
+            x2, _ = ops.gemm(u, w.w["proj"], lib.EPI_BIAS_RES_F32, bias=w.b["proj"], res=x1)
+            if save is not None:
+                save.append(dict(x0=x, mu1=mu1, rs1=rs1, qkv=qkv, lse=lse, x1=x1, mu2=mu2, rs2=rs2, h=h))
+            x = x2
+        return x
+
+    def backward(self, dxf, dxb, nseq: int, L: int, saved: list, grads: List[Dict[str, torch.Tensor]],
+                 accumulate: bool):
+        """dxf fp32 / dxb bf16 [nseq*L, C]: gradient w.r.t. the stack output for the FIRST nseq sequences of
+        the saved forward.  grads[i] = dict(ln1_w, ln1_b, ln2_w, ln2_b) receive d(gamma), d(beta)."""
+        M = nseq * L
+        for w, s, g in zip(reversed(self.blocks), reversed(saved), reversed(grads)):
+            dh, _ = ops.gemm(dxb, w.wT["proj"], lib.EPI_GELU_BWD, aux=s["h"])
+            dy2, _ = ops.gemm(dh, w.wT["fc"], lib.EPI_BF16)
+            dxf, dxb = ops.ln_bwd(dy2, s["x1"][:M], w.ln2_w, s["mu2"], s["rs2"], dres=dxf, dgamma=g["ln2_w"],
+                                  dbeta=g["ln2_b"], accumulate=accumulate, inplace_res=True)
+            do, _ = ops.gemm(dxb, w.wT["o"], lib.EPI_BF16)
+            dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal)
+            dy1, _ = ops.gemm(dqkv, w.wT["qkv"], lib.EPI_BF16)
+            dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, dgamma=g["ln1_w"],
+                                  dbeta=g["ln1_b"], accumulate=accumulate, inplace_res=True)
+        return dxf, dxb
+
+
+class TextTower:
+    """CLIP.encode_text (open_clip/model.py:269-286)."""
+
+    def __init__(self, model, need_bwd: bool = True):
+        self.model = model
+        C = model.positional_embedding.shape[1]
+        self.C, self.D = C, model.text_projection.shape[1]
+        self.heads = C // 64
+        self.stack = Stack(model.transformer, self.heads, True, need_bwd)
+        self.tok = model.token_embedding.weight.detach()
+        self.pos = model.positional_embedding.detach()
+        self.lnf_w, self.lnf_b = model.ln_final.weight.detach(), model.ln_final.bias.detach()
+        self.proj = model.text_projection.detach().contiguous()
+
+    def forward(self, tokens, normalize: bool, save: bool):
+        """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx)"""
+        tokens = tokens.contiguous()
+        nseq, L = tokens.shape
+        x = ops.embed_fwd(tokens, self.tok, self.pos)
+        saved = [] if save else None
+        x = self.stack.forward(x, nseq, L, saved)
+        eot = ops.eot_index(tokens)
+        feat, head = ops.pool_proj_fwd(x, eot, self.lnf_w, self.lnf_b, self.proj, nseq, L, normalize, save=save)
+        ctx = dict(saved=saved, eot=eot, head=head, feat=feat, nseq=nseq, L=L, normalize=normalize) if save else None
+        return feat, ctx
+
+    def backward(self, ctx, dfeat, grads, accumulate: bool):
+        """dfeat fp32 [n_grad, D] for the first n_grad sequences of the forward."""
+        n, L = dfeat.shape[0], ctx["L"]
+        dxf = torch.zeros(n * L, self.C, dtype=f32, device=dfeat.device)
+        dxb = torch.zeros(n * L, self.C, dtype=bf16, device=dfeat.device)
+        ops.pool_proj_bwd(dfeat.contiguous(), ctx["feat"], ctx["head"], self.lnf_w, self.proj, ctx["eot"], n, L,
+                          ctx["normalize"], dxf, dxb)
+        self.stack.backward(dxf, dxb, n, L, ctx["saved"], grads, accumulate)
+
+
+class VisionTower:
+    """CLIP.encode_image -> VisionTransformer.forward (open_clip/transformer.py:502-547), forward only."""
+
+    def __init__(self, model):
+        v = model.visual
+        self.C = v.conv1.weight.shape[0]
+        self.patch = v.conv1.weight.shape[-1]
+        self.D = v.proj.shape[1]
+        K = 3 * self.patch * self.patch
+        self.Kpad = (K + 63) // 64 * 64
+        w = v.conv1.weight.detach().reshape(self.C, K)
+        if self.Kpad != K:
+            w = torch.nn.functional.pad(w, (0, self.Kpad - K))
+        self.w_patch = ops.cast_bf16(w.contiguous())
+        self.cls = v.class_embedding.detach()
+        self.pos = v.positional_embedding.detach()
+        self.lnpre = (v.ln_pre.weight.detach(), v.ln_pre.bias.detach())
+        self.lnpost = (v.ln_post.weight.detach(), v.ln_post.bias.detach())
+        self.proj = v.proj.detach().contiguous()
+        self.stack = Stack(v.transformer, self.C // 64, False, need_bwd=False)
+
+    def forward(self, images, normalize: bool):
+        images = images.contiguous().float()
+        n, _, H, W = images.shape
+        P = (H // self.patch) * (W // self.patch)
+        if P + 1 != self.pos.shape[0]:
+            raise RuntimeError(f"encode_image: image {H}x{W} gives {P + 1} tokens, model expects {self.pos.shape[0]}")
+        patches = ops.patchify(images, self.patch, self.Kpad)
+        pe, _ = ops.gemm(patches, self.w_patch, lib.EPI_F32)
+        x = ops.vision_embed(pe, self.cls, self.pos, self.lnpre[0], self.lnpre[1], n, P)
+        x = self.stack.forward(x, n, P + 1, None)
+        feat, _ = ops.pool_proj_fwd(x, None, self.lnpost[0], self.lnpost[1], self.proj, n, P + 1, normalize, save=False)
+        return feat

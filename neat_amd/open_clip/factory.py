@@ -1,0 +1,104 @@
+"""Model construction and the parameter-selection helpers of NEAT's TTA path.
+
+``freeze_parameters`` / ``collect_params`` follow reference open_clip/factory.py:395-437 exactly: they
+define WHICH parameters adapt (LayerNorm affine under ``model.transformer`` for t2i, under
+``model.visual`` for i2t) and in which order the optimizer sees them.
+"""
+from __future__ import annotations
+
+import json
+import os
+from copy import deepcopy
+from pathlib import Path
+from typing import Optional, Union
+
+import torch
+
+from ..synth import MODEL_CFGS
+from .model import CLIP, VideoCLIP
+
+_MODEL_CONFIGS = {k: deepcopy(v) for k, v in MODEL_CFGS.items()}
+
+
+def list_models():
+    return list(_MODEL_CONFIGS.keys())
+
+
+def add_model_config(path):
+    """Register architecture JSON file(s) (reference factory.py:62-67)."""
+    path = Path(path)
+    files = [path] if path.is_file() else sorted(path.glob("*.json"))
+    for cf in files:
+        with open(cf) as f:
+            cfg = json.load(f)
+        if all(a in cfg for a in ("embed_dim", "vision_cfg", "text_cfg")):
+            _MODEL_CONFIGS[cf.stem] = cfg
+
+
+def get_model_config(model_name):
+    return deepcopy(_MODEL_CONFIGS.get(model_name.replace("/", "-")))
+
+
+def load_checkpoint(model, checkpoint_path, strict=True):
+    sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    if next(iter(sd)).startswith("module"):
+        sd = {k[7:]: v for k, v in sd.items()}
+    for k in ("input_resolution", "context_length", "vocab_size"):
+        sd.pop(k, None)
+    return model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=strict)
+
+
+def create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32",
+                 device: Union[str, torch.device] = "cpu", force_quick_gelu: bool = False, **model_kwargs):
+    """reference factory.py:166-321.  ``pretrained`` may be a local checkpoint path; named tags need the
+    network and are unavailable offline.  ``precision`` is accepted for CLI compatibility: master weights
+    stay fp32 and the kernels compute bf16 x bf16 -> fp32 regardless."""
+    cfg = get_model_config(model_name)
+    if cfg is None:
+        raise RuntimeError(f"Model config for {model_name} not found; available: {list_models()}")
+    cfg = dict(cfg, **{k: v for k, v in model_kwargs.items() if k in ("embed_dim", "vision_cfg", "text_cfg")})
+    model = CLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)
+    if pretrained:
+        if os.path.exists(pretrained):
+            load_checkpoint(model, pretrained)
+        else:
+            raise RuntimeError(f"Pretrained weights ({pretrained}) not found locally; named tags need network access")
+    model.to(device=torch.device(device))
+    return model
+
+
+def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32",
+                                device: Union[str, torch.device] = "cpu", video: bool = False, **kw):
+    """reference factory.py:445-510.  Image preprocessing is host-side I/O outside the accelerated path;
+    the returned transforms are ``None`` (callers feed preprocessed tensors)."""
+    kw.pop("image_mean", None); kw.pop("image_std", None)
+    model = create_model(model_name, pretrained, precision=precision, device=device, **kw)
+    if video:
+        model = VideoCLIP(model)
+    return model, None, None
+
+
+def freeze_parameters(model, only_visual):
+    """reference factory.py:395-409."""
+    model.train()
+    model.requires_grad_(False)
+    tower = model.visual if only_visual else model.transformer
+    for name, param in tower.named_parameters():
+        if "ln" in name:
+            param.requires_grad_(True)
+    return model
+
+
+def collect_params(model, only_visual):
+    """reference factory.py:411-437: (params, names) of LayerNorm weight/bias in module-walk order."""
+    params, names = [], []
+    tower = model.visual if only_visual else model.transformer
+    for nm, m in tower.named_modules():
+        if isinstance(m, torch.nn.LayerNorm):
+            for np_, p in m.named_parameters():
+                if np_ in ("weight", "bias"):
+                    params.append(p)
+                    names.append(f"{nm}.{np_}")
+    return params, names

@@ -1,0 +1,318 @@
+"""Tensor-level wrappers over the C ABI (include/neat_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation is a HIP kernel of
+libneat_hip.so.  Wrappers validate dtype / contiguity / device (the kernels index raw pointers) and
+raise RuntimeError on any failure -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib
+
+bf16, f32, i32, i64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+# bench.py installs a KernelTimer here to bracket ONE kernel's launches with HIP events (on the stream the
+# kernel runs on) during the timed region; None in normal operation.
+KERNEL_TIMER = None
+
+
+class KernelTimer:
+    """Brackets the launches of one GEMM instance (epilogue id) with HIP events on the current stream."""
+
+    def __init__(self, epilogue: int):
+        self.epilogue = epilogue
+        self.events = []
+        self.shapes = []
+        self.enabled = False
+
+    def match(self, kind, epilogue, M, N, K):
+        return self.enabled and kind == "gemm" and epilogue == self.epilogue
+
+    def region(self, M, N, K):
+        timer = self
+
+        class _R:
+            def __enter__(self_r):
+                self_r.a = torch.cuda.Event(enable_timing=True)
+                self_r.b = torch.cuda.Event(enable_timing=True)
+                self_r.a.record(torch.cuda.current_stream())
+
+            def __exit__(self_r, *exc):
+                self_r.b.record(torch.cuda.current_stream())
+                timer.events.append((self_r.a, self_r.b))
+                timer.shapes.append((M, N, K))
+        return _R()
+
+    def summary(self):
+        """(avg ms per launch, avg algorithmic FLOP per launch, n launches) -- call after a sync."""
+        if not self.events:
+            return 0.0, 0.0, 0
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        fl = [2.0 * m * n * k for m, n, k in self.shapes]
+        return sum(ms) / len(ms), sum(fl) / len(fl), len(ms)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (libneat_hip has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()
+
+
+# ---- LayerNorm ----
+def ln_fwd(x, gamma, beta, eps=1e-5, out_bf16=True, out_f32=False, save_stats=True):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(x.shape, dtype=bf16, device=x.device) if out_bf16 else None
+    yf = torch.empty(x.shape, dtype=f32, device=x.device) if out_f32 else None
+    mean = torch.empty(rows, dtype=f32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=f32, device=x.device) if save_stats else None
+    lib.call("neat_ln_fwd", _p(x, f32, "x"), _p(gamma, f32, "gamma"), _p(beta, f32, "beta"), _p(y), _p(yf),
+             _p(mean), _p(rstd), rows, cols, eps, _stream())
+    return y, yf, mean, rstd
+
+
+def ln_bwd(dy, x, gamma, mean, rstd, dres=None, want_f32=True, want_bf16=True, dgamma=None, dbeta=None,
+           accumulate=False, inplace_res=False):
+    """Returns (dx_f32, dx_bf16).  If dgamma/dbeta are given they receive (or accumulate) the parameter grads."""
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dxf = (dres if (inplace_res and dres is not None) else torch.empty(x.shape, dtype=f32, device=x.device)) \
+        if want_f32 else None
+    dxb = torch.empty(x.shape, dtype=bf16, device=x.device) if want_bf16 else None
+    partial = None
+    if dgamma is not None:
+        nblk = lib.load().neat_ln_bwd_blocks(rows)
+        partial = torch.empty(nblk, 2, cols, dtype=f32, device=x.device)
+    lib.call("neat_ln_bwd", _p(dy, bf16, "dy"), _p(x, f32, "x"), _p(gamma, f32, "gamma"), _p(mean, f32), _p(rstd, f32),
+             _p(dres, f32), _p(dxf), _p(dxb), _p(partial), rows, cols, _stream())
+    if dgamma is not None:
+        lib.call("neat_ln_bwd_finalize", _p(partial), partial.shape[0], cols, _p(dgamma, f32, "dgamma"),
+                 _p(dbeta, f32, "dbeta"), int(accumulate), _stream())
+    return dxf, dxb
+
+
+# ---- GEMM ----
+def gemm(A, W, epilogue, bias=None, res=None, aux=None, out0=None, out1=None):
+    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); allocates outputs that are not passed in."""
+    M, K = A.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise RuntimeError(f"gemm: K mismatch {A.shape} x {W.shape}")
+    dev = A.device
+    if out0 is None and not (epilogue == lib.EPI_BIAS_GELU and False):
+        out0 = torch.empty(M, N, dtype=f32 if epilogue in (lib.EPI_BIAS_RES_F32, lib.EPI_F32) else bf16, device=dev)
+    if epilogue == lib.EPI_BIAS_GELU and out1 is None:
+        out1 = torch.empty(M, N, dtype=bf16, device=dev)
+    for t, nm in ((bias, "bias"), (res, "res")):
+        if t is not None and t.dtype != f32:
+            raise RuntimeError(f"gemm: {nm} must be float32")
+    if bias is not None and bias.numel() != N:
+        raise RuntimeError("gemm: bias size mismatch")
+    if res is not None and tuple(res.shape) != (M, N):
+        raise RuntimeError("gemm: residual shape mismatch")
+    if aux is not None and (aux.dtype != bf16 or aux.shape[1] != N or aux.shape[0] < M):
+        raise RuntimeError("gemm: aux shape/dtype mismatch")
+    t = KERNEL_TIMER
+    if t is not None and t.match("gemm", epilogue, M, N, K):
+        with t.region(M, N, K):
+            lib.call("neat_gemm_bf16", _p(A, bf16, "A"), _p(W, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0),
+                     _p(out1), M, N, K, epilogue, _stream())
+        return out0, out1
+    lib.call("neat_gemm_bf16", _p(A, bf16, "A"), _p(W, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0), _p(out1),
+             M, N, K, epilogue, _stream())
+    return out0, out1
+
+
+# ---- attention ----
+def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True):
+    C = heads * 64
+    if tuple(qkv.shape) != (nseq * L, 3 * C):
+        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(nseq * L, 3 * C)}")
+    out = torch.empty(nseq * L, C, dtype=bf16, device=qkv.device)
+    lse = torch.empty(nseq, heads, L, dtype=f32, device=qkv.device) if save_lse else None
+    lib.call("neat_attn_fwd", _p(qkv, bf16, "qkv"), _p(out), _p(lse), nseq, L, heads, int(causal), _stream())
+    return out, lse
+
+
+def attn_bwd(qkv, dout, lse, nseq, L, heads, causal):
+    C = heads * 64
+    if qkv.shape[0] < nseq * L or qkv.shape[1] != 3 * C or tuple(dout.shape) != (nseq * L, C):
+        raise RuntimeError("attn_bwd: shape mismatch")
+    dqkv = torch.empty(nseq * L, 3 * C, dtype=bf16, device=qkv.device)
+    lib.call("neat_attn_bwd", _p(qkv, bf16, "qkv"), _p(dout, bf16, "dout"), _p(lse, f32, "lse"), _p(dqkv), nseq, L,
+             heads, int(causal), _stream())
+    return dqkv
+
+
+# ---- embedding / pooled head ----
+def embed_fwd(tokens, tok_emb, pos_emb):
+    nseq, L = tokens.shape
+    vocab, C = tok_emb.shape
+    if pos_emb.shape[0] < L or pos_emb.shape[1] != C:
+        raise RuntimeError("embed_fwd: positional embedding too short")
+    x = torch.empty(nseq * L, C, dtype=f32, device=tokens.device)
+    lib.call("neat_embed_fwd", _p(tokens, i64, "tokens"), _p(tok_emb, f32, "tok_emb"), _p(pos_emb, f32, "pos_emb"),
+             _p(x), nseq, L, C, vocab, _stream())
+    return x
+
+
+def eot_index(tokens):
+    nseq, L = tokens.shape
+    eot = torch.empty(nseq, dtype=i32, device=tokens.device)
+    lib.call("neat_eot_index", _p(tokens, i64, "tokens"), _p(eot), nseq, L, _stream())
+    return eot
+
+
+def pool_proj_fwd(x, row_idx, gamma, beta, proj, nseq, L, normalize, save=True, eps=1e-5):
+    C, D = proj.shape
+    if x.shape[0] < nseq * L or x.shape[1] != C:
+        raise RuntimeError("pool_proj_fwd: shape mismatch")
+    dev = x.device
+    feat = torch.empty(nseq, D, dtype=f32, device=dev)
+    xe = torch.empty(nseq, C, dtype=f32, device=dev) if save else None
+    mean = torch.empty(nseq, dtype=f32, device=dev) if save else None
+    rstd = torch.empty(nseq, dtype=f32, device=dev) if save else None
+    nrm = torch.empty(nseq, dtype=f32, device=dev) if save else None
+    lib.call("neat_pool_proj_fwd", _p(x, f32, "x"), _p(row_idx, i32), _p(gamma, f32), _p(beta, f32), _p(proj, f32),
+             _p(feat), _p(xe), _p(mean), _p(rstd), _p(nrm), nseq, L, C, D, int(normalize), eps, _stream())
+    return feat, (xe, mean, rstd, nrm)
+
+
+def pool_proj_bwd(dfeat, feat, saved, gamma, proj, row_idx, nseq, L, normalize, dxf, dxb):
+    xe, mean, rstd, nrm = saved
+    C, D = proj.shape
+    lib.call("neat_pool_proj_bwd", _p(dfeat, f32, "dfeat"), _p(feat, f32), _p(nrm, f32), _p(xe, f32), _p(mean, f32),
+             _p(rstd, f32), _p(gamma, f32), _p(proj, f32), _p(row_idx, i32), _p(dxf, f32), _p(dxb, bf16), nseq, L, C, D,
+             int(normalize), _stream())
+
+
+# ---- vision stem ----
+def patchify(images, patch, Kpad):
+    n, c, H, W = images.shape
+    if c != 3:
+        raise RuntimeError("patchify: expected 3 channels")
+    out = torch.empty(n * (H // patch) * (W // patch), Kpad, dtype=bf16, device=images.device)
+    lib.call("neat_patchify", _p(images, f32, "images"), _p(out), n, H, W, patch, Kpad, _stream())
+    return out
+
+
+def vision_embed(patch_emb, cls, pos, gamma, beta, n, P, eps=1e-5):
+    C = patch_emb.shape[1]
+    x = torch.empty(n * (P + 1), C, dtype=f32, device=patch_emb.device)
+    lib.call("neat_vision_embed", _p(patch_emb, f32), _p(cls, f32), _p(pos, f32), _p(gamma, f32), _p(beta, f32), _p(x),
+             n, P, C, eps, _stream())
+    return x
+
+
+def frame_mean_norm(feat, n, F):
+    D = feat.shape[1]
+    out = torch.empty(n, D, dtype=f32, device=feat.device)
+    lib.call("neat_frame_mean_norm", _p(feat, f32, "feat"), _p(out), n, F, D, _stream())
+    return out
+
+
+# ---- coarse alignment / loss / optimizer ----
+def coarse_align(q, pos, neg, G):
+    B, D = q.shape
+    N = G.shape[0]
+    dev = q.device
+    S = torch.empty(B, N, dtype=f32, device=dev)
+    idx = torch.empty(B, dtype=i32, device=dev)
+    coarse = torch.empty(B, D, dtype=f32, device=dev)
+    ws = torch.empty(lib.load().neat_coarse_ws_floats(B, N), dtype=f32, device=dev)
+    lib.call("neat_coarse_align", _p(q, f32, "q"), _p(pos, f32, "pos"), _p(neg, f32, "neg"), _p(G, f32, "G"), _p(S),
+             _p(idx), _p(coarse), _p(ws), B, N, D, _stream())
+    return coarse, idx, S
+
+
+def tta_loss_fwd_bwd(text, pos, inv, text_all, coarse_all, T1, T2, row0=0):
+    Bl, D = text.shape
+    B = text_all.shape[0]
+    dev = text.device
+    losses = torch.empty(3, dtype=f32, device=dev)
+    dt = torch.empty(Bl, D, dtype=f32, device=dev)
+    dp = torch.empty(Bl, D, dtype=f32, device=dev)
+    dv = torch.empty(Bl, D, dtype=f32, device=dev)
+    ws = torch.empty(lib.load().neat_loss_ws_floats(B, Bl), dtype=f32, device=dev)
+    lib.call("neat_tta_loss_fwd_bwd", _p(text, f32, "text"), _p(pos, f32, "pos"), _p(inv, f32, "inv"),
+             _p(text_all, f32, "text_all"), _p(coarse_all, f32, "coarse_all"), float(T1), float(T2), _p(losses), _p(dt),
+             _p(dp), _p(dv), _p(ws), B, Bl, row0, D, _stream())
+    return losses, dt, dp, dv
+
+
+def adamw_flat(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0):
+    lib.call("neat_adamw_flat", _p(p, f32, "p"), _p(g, f32, "g"), _p(m, f32, "m"), _p(v, f32, "v"), p.numel(), float(lr),
+             float(beta1), float(beta2), float(eps), float(wd), int(step), _stream())
+
+
+# ---- retrieval ----
+def _strides2d(t, name):
+    if t.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D tensor")
+    sr, sc = t.stride()
+    if t.shape[1] == 1:
+        sc = 1
+    if t.shape[0] == 1 and sc == 1:
+        sr = t.shape[1]
+    if sc != 1 and sr != 1:
+        raise RuntimeError(f"{name}: one stride must be 1 (got {t.stride()})")
+    return sr, sc
+
+
+def topk_rows(scores, k) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row-wise top-k (values, int32 indices) of a [R, N] fp32 matrix or of a transposed view of one."""
+    if not scores.is_cuda or scores.dtype != f32:
+        raise RuntimeError("topk_rows: expected a float32 GPU tensor")
+    R, N = scores.shape
+    sr, sc = _strides2d(scores, "scores")
+    idx = torch.empty(R, k, dtype=i32, device=scores.device)
+    val = torch.empty(R, k, dtype=f32, device=scores.device)
+    ws = torch.empty(lib.load().neat_topk_ws_bytes(R, N, k), dtype=torch.uint8, device=scores.device)
+    lib.call("neat_topk_rows", scores.data_ptr(), sr, sc, R, N, k, _p(idx), _p(val), _p(ws), _stream())
+    return val, idx
+
+
+def recall_from_topk(idx, positive_pairs):
+    if positive_pairs.dtype == torch.bool:
+        positive_pairs = positive_pairs.view(torch.uint8)
+    if positive_pairs.dtype != torch.uint8 or not positive_pairs.is_cuda:
+        raise RuntimeError("recall_from_topk: positives must be a bool/uint8 GPU tensor")
+    R, N = positive_pairs.shape
+    sr, sc = _strides2d(positive_pairs, "positive_pairs")
+    out = torch.empty(R, dtype=f32, device=idx.device)
+    lib.call("neat_recall_from_topk", _p(idx, i32, "idx"), positive_pairs.data_ptr(), sr, sc, R, N, idx.shape[1], _p(out),
+             _stream())
+    return out
+
+
+def gemm_f32_nt(A, B):
+    M, K = A.shape
+    N = B.shape[0]
+    Cm = torch.empty(M, N, dtype=f32, device=A.device)
+    lib.call("neat_gemm_f32_nt", _p(A, f32, "A"), _p(B, f32, "B"), _p(Cm), M, N, K, _stream())
+    return Cm
+
+
+def cast_bf16(src):
+    dst = torch.empty(src.shape, dtype=bf16, device=src.device)
+    lib.call("neat_cast_bf16", _p(src, f32, "src"), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def transpose_cast_bf16(src):
+    R, Cc = src.shape
+    dst = torch.empty(Cc, R, dtype=bf16, device=src.device)
+    lib.call("neat_transpose_cast_bf16", _p(src, f32, "src"), _p(dst), R, Cc, _stream())
+    return dst

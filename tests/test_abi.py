@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads and exports every symbol include/neat_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "neat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(neat_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_entry_points():
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for must in ("neat_ln_fwd", "neat_ln_bwd", "neat_gemm_bf16", "neat_attn_fwd", "neat_attn_bwd",
+                 "neat_coarse_align", "neat_tta_loss_fwd_bwd", "neat_adamw_flat", "neat_topk_rows"):
+        assert must in syms
+
+
+def test_library_exports_all_declared_symbols():
+    from neat_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.fail(f"{lib.LIB_PATH} missing: run __graft_entry__.build()")
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(dll, s), f"symbol {s} not exported"
+    assert set(_declared_symbols()) == set(lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    dll.neat_version.restype = ctypes.c_char_p
+    assert b"gfx950" in dll.neat_version()
+
+
+def test_pure_host_entry_points():
+    """Entry points that do no device work can be called without a GPU."""
+    from neat_amd import lib
+    L = lib.load()
+    assert L.neat_ln_bwd_blocks(78848) >= 1
+    assert L.neat_coarse_ws_floats(256, 5000) == 2 * 256 * 79
+    assert L.neat_loss_ws_floats(256, 256) == 256 * 256 * 2 + 256 + 3 * 256
+    assert L.neat_topk_ws_bytes(5000, 25014, 10) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Shape/pointer validation happens before any HIP call and reports through neat_last_error()."""
+    from neat_amd import lib
+    L = lib.load()
+    rc = L.neat_gemm_bf16(None, None, None, None, None, None, None, 8, 8, 64, 0, None)
+    assert rc == -2 and "null" in lib.last_error()
+    rc = L.neat_ln_fwd(1, 1, 1, 1, None, None, None, 4, 1030, 1e-5, None)
+    assert rc == -1 and "cols" in lib.last_error()
+    rc = L.neat_topk_rows(1, 7, 3, 4, 4, 2, 1, None, None, None)
+    assert rc == -1
+
+
+def test_product_path_has_no_oracle_import():
+    """The shipped package must never import the oracle (parity claims depend on it)."""
+    pkg = os.path.join(ROOT, "neat_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f

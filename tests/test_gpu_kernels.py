@@ -1,0 +1,389 @@
+"""GPU: every HIP kernel, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances: kernels that compute in fp32 (loss, coarse alignment, AdamW, top-k, pooled head) are held to
+fp32 round-off; bf16-operand kernels (GEMM, attention, LN output) to bf16 round-off (2^-8 relative per
+element, checked as a relative L2 error of the whole tensor against an fp32 oracle fed the SAME
+bf16-rounded inputs).  Integer / index outputs are bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+from neat_amd import lib, ops  # noqa: E402
+from oracle import neat_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,cols", [(1, 128), (1000, 512), (77 * 13, 768), (333, 1024), (50, 4)])
+def test_ln_fwd_bwd(rows, cols):
+    x = torch.randn(rows, cols, generator=g(1)) * 2 + 0.5
+    gam = torch.randn(cols, generator=g(2)) * 0.2 + 1
+    bet = torch.randn(cols, generator=g(3)) * 0.1
+    y_ref, mu_ref, rs_ref = O.layer_norm_fwd(x, gam, bet)
+    y, yf, mu, rs = ops.ln_fwd(x.to(DEV), gam.to(DEV), bet.to(DEV), out_f32=True)
+    assert rel_l2(yf.cpu(), y_ref) < 2e-6
+    assert rel_l2(y.float().cpu(), y_ref) < 4e-3
+    assert torch.equal(y.cpu(), bf(yf.cpu()))                      # bf16 output = RNE of the fp32 result
+    assert rel_l2(mu.cpu(), mu_ref) < 1e-5 and rel_l2(rs.cpu(), rs_ref) < 1e-5
+    dy = bf(torch.randn(rows, cols, generator=g(4)))
+    dres = torch.randn(rows, cols, generator=g(5))
+    dx_ref, dg_ref, db_ref = O.layer_norm_bwd(dy.float(), x, mu_ref, rs_ref, gam)
+    dg = torch.zeros(cols, device=DEV)
+    db = torch.zeros(cols, device=DEV)
+    dxf, dxb = ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, dres=dres.to(DEV), dgamma=dg, dbeta=db)
+    assert rel_l2(dxf.cpu(), dx_ref + dres) < 1e-5
+    assert torch.equal(dxb.cpu(), bf(dxf.cpu()))
+    assert rel_l2(dg.cpu(), dg_ref) < 1e-5 and rel_l2(db.cpu(), db_ref) < 1e-5
+    # accumulate=1 adds on top; no-residual / no-parameter-gradient variant
+    ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, dgamma=dg, dbeta=db, accumulate=True)
+    assert rel_l2(dg.cpu(), 2 * dg_ref) < 1e-5
+    dxf2, _ = ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, want_bf16=False)
+    assert rel_l2(dxf2.cpu(), dx_ref) < 1e-5
+
+
+def test_ln_is_deterministic():
+    x = torch.randn(5000, 512, generator=g(1)).to(DEV)
+    gam = torch.ones(512, device=DEV)
+    _, _, mu, rs = ops.ln_fwd(x, gam, gam)
+    dy = bf(torch.randn(5000, 512, generator=g(2))).to(DEV)
+    outs = []
+    for _ in range(2):
+        dg = torch.zeros(512, device=DEV); db = torch.zeros(512, device=DEV)
+        ops.ln_bwd(dy, x, gam, mu, rs, dgamma=dg, dbeta=db)
+        outs.append((dg.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------ GEMM
+SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 64), (512, 512, 2048), (77, 1536, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_epilogues(M, N, K):
+    A = bf(torch.randn(M, K, generator=g(1)))
+    W = bf(torch.randn(N, K, generator=g(2)) * K ** -0.5)
+    bias = torch.randn(N, generator=g(3)) * 0.1
+    res = torch.randn(M, N, generator=g(4))
+    ref = A.float() @ W.float().t()
+    Ad, Wd, bd, rd = A.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
+    tol = 6e-3
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16)
+    assert rel_l2(o.float().cpu(), ref) < tol
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_F32)
+    assert rel_l2(o.cpu(), ref) < 1e-5
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_BF16, bias=bd)
+    assert rel_l2(o.float().cpu(), ref + bias) < tol
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=rd)
+    assert rel_l2(o.cpu(), ref + bias + res) < 1e-5
+    # in-place residual
+    r2 = rd.clone()
+    ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=r2, out0=r2)
+    assert rel_l2(r2.cpu(), ref + bias + res) < 1e-5
+    h, u = ops.gemm(Ad, Wd, lib.EPI_BIAS_GELU, bias=bd)
+    assert rel_l2(h.float().cpu(), ref + bias) < tol
+    assert rel_l2(u.float().cpu(), O.quick_gelu(h.float().cpu())) < tol
+    aux = bf(torch.randn(M, N, generator=g(5)))
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_GELU_BWD, aux=aux.to(DEV))
+    assert rel_l2(o.float().cpu(), ref * O.quick_gelu_grad(aux.float())) < tol
+
+
+def test_gemm_exact_small_integers():
+    """A = I (padded) with an ASYMMETRIC integer W catches a transposed C write or a wrong k order."""
+    M = N = 256
+    K = 256
+    A = torch.eye(M, K)
+    W = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 7) % 61 - 30.0
+    o, _ = ops.gemm(bf(A).to(DEV), bf(W).to(DEV), lib.EPI_F32)
+    assert torch.equal(o.cpu(), (A @ W.t()))
+    A2 = torch.randint(-4, 5, (333, 192), generator=g(1)).float()
+    W2 = torch.randint(-4, 5, (80, 192), generator=g(2)).float()
+    o, _ = ops.gemm(bf(A2).to(DEV), bf(W2).to(DEV), lib.EPI_F32)
+    assert torch.equal(o.cpu(), A2 @ W2.t())
+
+
+def test_gemm_rejects_bad_shapes():
+    A = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
+    W = torch.zeros(16, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="K"):
+        ops.gemm(A, W, lib.EPI_BF16)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_case(nseq, L, heads, causal, seed, bwd=True):
+    C = heads * 64
+    qkv = bf(torch.randn(nseq * L, 3 * C, generator=g(seed)) * 0.8)
+    o_ref, p = O.attention_fwd(qkv.float().view(nseq, L, 3 * C), heads, causal)
+    o, lse = ops.attn_fwd(qkv.to(DEV), nseq, L, heads, causal)
+    assert rel_l2(o.float().cpu(), o_ref.reshape(nseq * L, C)) < 8e-3
+    # lse against the oracle's scores
+    q, k, _ = (t.view(nseq, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().view(nseq, L, 3 * C).split(C, -1))
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, -1), atol=2e-3)
+    if not bwd:
+        return
+    do = bf(torch.randn(nseq * L, C, generator=g(seed + 1)))
+    d_ref = O.attention_bwd(do.float().view(nseq, L, C), qkv.float().view(nseq, L, 3 * C), p, heads)
+    d = ops.attn_bwd(qkv.to(DEV), do.to(DEV), lse, nseq, L, heads, causal)
+    d_ref = d_ref.reshape(nseq * L, 3 * C)
+    for nm, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        assert rel_l2(d.float().cpu()[:, sl], d_ref[:, sl]) < 1.5e-2, nm
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", [(3, 77, 8, True), (5, 77, 12, True), (2, 50, 12, False),
+                                                  (4, 16, 2, True), (3, 5, 2, False), (2, 64, 1, True),
+                                                  (7, 80, 2, False), (1, 33, 3, True)])
+def test_attention_fwd_bwd(nseq, L, heads, causal):
+    _attn_case(nseq, L, heads, causal, 10 + L)
+
+
+@pytest.mark.parametrize("L,heads", [(197, 12), (257, 16), (100, 2)])
+def test_attention_fwd_long_vision(L, heads):
+    _attn_case(2, L, heads, False, 50 + L, bwd=False)
+
+
+def test_attention_bwd_subset_of_sequences():
+    """Backward over the first n sequences of a larger forward (the neg stream has no backward)."""
+    nseq, L, heads = 6, 77, 8
+    C = heads * 64
+    qkv = bf(torch.randn(nseq * L, 3 * C, generator=g(3)))
+    _, lse = ops.attn_fwd(qkv.to(DEV), nseq, L, heads, True)
+    do = bf(torch.randn(4 * L, C, generator=g(4)))
+    d_part = ops.attn_bwd(qkv.to(DEV), do.to(DEV), lse, 4, L, heads, True)
+    do_full = torch.cat([do, torch.zeros(2 * L, C, dtype=torch.bfloat16)])
+    d_full = ops.attn_bwd(qkv.to(DEV), do_full.to(DEV), lse, nseq, L, heads, True)
+    assert torch.equal(d_part.cpu(), d_full.cpu()[: 4 * L])
+
+
+# ------------------------------------------------------------------ embedding / pooled head / stem
+def test_embed_and_eot():
+    vocab, C, L, n = 1000, 128, 16, 9
+    tok = torch.randint(0, vocab, (n, L), generator=g(1))
+    tok[0, 3] = vocab - 1; tok[0, 9] = vocab - 1          # duplicate maximum -> first wins
+    emb = torch.randn(vocab, C, generator=g(2)); pos = torch.randn(L, C, generator=g(3))
+    x = ops.embed_fwd(tok.to(DEV), emb.to(DEV), pos.to(DEV))
+    assert torch.equal(x.cpu(), (emb[tok] + pos).view(n * L, C))
+    assert torch.equal(ops.eot_index(tok.to(DEV)).cpu().long(), tok.argmax(-1))
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_pool_proj_fwd_bwd(normalize):
+    n, L, C, D = 11, 16, 128, 512
+    x = torch.randn(n * L, C, generator=g(1))
+    idx = torch.randint(0, L, (n,), generator=g(2)).int()
+    gam = torch.randn(C, generator=g(3)) * 0.2 + 1; bet = torch.randn(C, generator=g(4)) * 0.1
+    proj = torch.randn(C, D, generator=g(5)) * C ** -0.5
+    xe = x.view(n, L, C)[torch.arange(n), idx.long()]
+    z, mu, rs = O.layer_norm_fwd(xe, gam, bet)
+    f = z @ proj
+    ref, nrm = O.l2_normalize(f) if normalize else (f, None)
+    feat, saved = ops.pool_proj_fwd(x.to(DEV), idx.to(DEV), gam.to(DEV), bet.to(DEV), proj.to(DEV), n, L, normalize)
+    assert rel_l2(feat.cpu(), ref) < 1e-5
+    dfeat = torch.randn(n, D, generator=g(6))
+    df = O.l2_normalize_bwd(dfeat, ref, nrm) if normalize else dfeat
+    dxe, _, _ = O.layer_norm_bwd(df @ proj.t(), xe, mu, rs, gam)
+    dxf = torch.zeros(n * L, C, device=DEV); dxb = torch.zeros(n * L, C, dtype=torch.bfloat16, device=DEV)
+    ops.pool_proj_bwd(dfeat.to(DEV), feat, saved, gam.to(DEV), proj.to(DEV), idx.to(DEV), n, L, normalize, dxf, dxb)
+    full = torch.zeros(n, L, C); full[torch.arange(n), idx.long()] = dxe
+    assert rel_l2(dxf.cpu(), full.view(n * L, C)) < 2e-5
+    assert torch.equal(dxb.cpu(), bf(dxf.cpu()))
+
+
+def test_patchify_and_vision_embed():
+    n, H, patch, C = 3, 32, 16, 128
+    img = torch.randn(n, 3, H, H, generator=g(1))
+    K = 3 * patch * patch
+    p = ops.patchify(img.to(DEV), patch, K)
+    assert torch.equal(p.cpu(), bf(O.patchify(img, patch).reshape(-1, K)))
+    p2 = ops.patchify(img.to(DEV), patch, K + 64)
+    assert torch.equal(p2.cpu()[:, :K], p.cpu()) and p2.cpu()[:, K:].float().abs().sum() == 0
+    P = (H // patch) ** 2
+    pe = torch.randn(n * P, C, generator=g(2)); cls = torch.randn(C, generator=g(3))
+    pos = torch.randn(P + 1, C, generator=g(4)); gam = torch.rand(C, generator=g(5)) + 0.5; bet = torch.randn(C, generator=g(6))
+    x = ops.vision_embed(pe.to(DEV), cls.to(DEV), pos.to(DEV), gam.to(DEV), bet.to(DEV), n, P)
+    ref = torch.cat([cls.view(1, 1, C).expand(n, 1, C), pe.view(n, P, C)], 1) + pos
+    ref = O.layer_norm_fwd(ref, gam, bet)[0]
+    assert rel_l2(x.cpu(), ref.reshape(-1, C)) < 2e-6
+
+
+def test_frame_mean_norm():
+    f = torch.nn.functional.normalize(torch.randn(5 * 4, 512, generator=g(1)), dim=-1)
+    out = ops.frame_mean_norm(f.to(DEV), 5, 4)
+    assert rel_l2(out.cpu(), O.l2_normalize(f.view(5, 4, 512).mean(1))[0]) < 1e-6
+
+
+def test_casts():
+    w = torch.randn(300, 130, generator=g(1))
+    assert torch.equal(ops.cast_bf16(w.to(DEV)).cpu(), bf(w))
+    assert torch.equal(ops.transpose_cast_bf16(w.to(DEV)).cpu(), bf(w.t().contiguous()))
+
+
+# ------------------------------------------------------------------ coarse alignment / loss / AdamW
+def _unit(n, d, seed):
+    return torch.nn.functional.normalize(torch.randn(n, d, generator=g(seed)), dim=-1)
+
+
+@pytest.mark.parametrize("B,N,D", [(24, 6, 32), (256, 5000, 512), (182, 777, 768), (3, 1, 16)])
+def test_coarse_align(B, N, D):
+    t, p, n, G = _unit(B, D, 1), _unit(B, D, 2), _unit(B, D, 3), _unit(N, D, 4)
+    c_ref, idx_ref, S_ref = O.coarse_align_t2i(t, p, n, G)
+    c, idx, S = ops.coarse_align(t.to(DEV), p.to(DEV), n.to(DEV), G.to(DEV))
+    np.testing.assert_allclose(S.cpu().numpy(), S_ref.numpy(), atol=2e-6)
+    # the argmax may legitimately differ only where fp32 summation order moves a near-tie
+    A = (p.double() @ G.double().t()) * (1 - torch.relu(n.double() @ G.double().t()))
+    bad = idx.cpu().long() != idx_ref
+    if bad.any():
+        gap = (A[bad].max(1)[0] - A[bad, idx.cpu().long()[bad]]).abs().max().item()
+        assert gap < 1e-6
+    assert torch.equal(c.cpu(), G[idx.cpu().long()])
+
+
+def test_coarse_align_ties_pick_first():
+    B, D = 8, 16
+    t, p, n = _unit(B, D, 1), _unit(B, D, 2), _unit(B, D, 3)
+    G = _unit(5, D, 4)
+    G = torch.cat([G, G, G])          # every gallery row appears three times -> exact ties
+    _, idx, _ = ops.coarse_align(t.to(DEV), p.to(DEV), n.to(DEV), G.to(DEV))
+    assert (idx.cpu() < 5).all()
+
+
+def test_loss_fwd_bwd_golden_ties():
+    """Inputs and expected values produced by the REFERENCE functions + autograd (tests/golden/loss_ties.npz)."""
+    z = load_golden("loss_ties")
+    t, p, n, v, G = (torch.from_numpy(z[k]) for k in ("t", "p", "n", "v", "G"))
+    c, idx, S = ops.coarse_align(t.to(DEV), p.to(DEV), n.to(DEV), G.to(DEV))
+    assert np.array_equal(idx.cpu().numpy(), z["idx"])
+    np.testing.assert_allclose(S.cpu().numpy(), z["S"], atol=1e-6)
+    losses, dt, dp, dv = ops.tta_loss_fwd_bwd(t.to(DEV), p.to(DEV), v.to(DEV), t.to(DEV), c, 0.03, 0.07)
+    np.testing.assert_allclose(losses.cpu().numpy(), z["losses"], rtol=2e-5)
+    np.testing.assert_allclose(dt.cpu().numpy(), z["dt"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(dp.cpu().numpy(), z["dp"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(dv.cpu().numpy(), z["dv"], atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,D", [(256, 512), (182, 768), (33, 64), (1000, 512)])
+def test_loss_fwd_bwd_vs_oracle(B, D):
+    t, p, v = _unit(B, D, 1), _unit(B, D, 2), _unit(B, D, 3)
+    t = torch.nn.functional.normalize(t + 0.5 * _unit(1, D, 9), dim=-1)
+    G = _unit(max(B // 3, 2), D, 4)
+    c = G[torch.randint(0, G.shape[0], (B,), generator=g(5))]     # shared coarse images -> SR ties
+    l_ref, dt_ref, dp_ref, dv_ref = O.tta_loss_fwd_bwd(t, p, v, c, 0.03, 0.07)
+    l, dt, dp, dv = ops.tta_loss_fwd_bwd(t.to(DEV), p.to(DEV), v.to(DEV), t.to(DEV), c.to(DEV), 0.03, 0.07)
+    np.testing.assert_allclose(l.cpu().numpy(), l_ref.numpy(), rtol=1e-4)
+    assert rel_l2(dt.cpu(), dt_ref) < 1e-3      # entropy grad is a difference of O(1) logits at T=0.03
+    assert rel_l2(dp.cpu(), dp_ref) < 1e-5 and rel_l2(dv.cpu(), dv_ref) < 1e-4
+
+
+def test_loss_row_shards_match_single_call():
+    """Data-parallel form: each rank's rows, global text/coarse -> same gradients; sr/tri sums add up."""
+    B, D = 96, 64
+    t, p, v, c = _unit(B, D, 1), _unit(B, D, 2), _unit(B, D, 3), _unit(B, D, 4)
+    td, pd, vd, cd = (x.to(DEV) for x in (t, p, v, c))
+    l, dt, dp, dv = ops.tta_loss_fwd_bwd(td, pd, vd, td, cd, 0.03, 0.07)
+    parts, ls = [], torch.zeros(3)
+    for lo, hi in ((0, 31), (31, 64), (64, 96)):
+        l_, a, b_, c_ = ops.tta_loss_fwd_bwd(td[lo:hi].contiguous(), pd[lo:hi].contiguous(), vd[lo:hi].contiguous(),
+                                             td, cd, 0.03, 0.07, row0=lo)
+        parts.append((a, b_, c_))
+        assert abs(l_[0].item() - l[0].item()) < 1e-6
+        ls[1:] += l_.cpu()[1:]
+    assert torch.equal(torch.cat([x[0] for x in parts]), dt)
+    assert torch.equal(torch.cat([x[1] for x in parts]), dp) and torch.equal(torch.cat([x[2] for x in parts]), dv)
+    np.testing.assert_allclose(ls[1:].numpy(), l.cpu()[1:].numpy(), rtol=1e-5)
+
+
+def test_adamw_matches_torch():
+    n = 24576
+    p0 = torch.randn(n, generator=g(1)); p_ref = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([p_ref], lr=2e-4, weight_decay=1e-3)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g(10 + step)) * 10 ** (-step)
+        p_ref.grad = gr.clone()
+        opt.step()
+        ops.adamw_flat(p, gr.to(DEV), m, v, step, 2e-4, wd=1e-3)
+        assert rel_l2(p.cpu(), p_ref.detach()) < 2e-7
+    st = opt.state[p_ref]
+    assert rel_l2(m.cpu(), st["exp_avg"]) < 1e-6 and rel_l2(v.cpu(), st["exp_avg_sq"]) < 1e-6
+
+
+# ------------------------------------------------------------------ retrieval scoring
+def test_topk_and_recall_golden():
+    z = load_golden("recall")
+    scores = torch.from_numpy(z["scores"]).to(DEV)
+    owner = torch.from_numpy(z["owner"]).long()
+    pos = torch.zeros(scores.shape, dtype=torch.bool)
+    pos[torch.arange(len(owner)), owner] = True
+    pos = pos.to(DEV)
+    from neat_amd.evaluation import retrieval as R
+    for k in (1, 5, 10):
+        val, idx = ops.topk_rows(scores, k)
+        assert np.array_equal(idx.cpu().numpy(), z[f"topk_t2i_{k}"])          # bit-exact indices (no ties)
+        assert torch.equal(val.cpu(), scores.cpu().gather(1, idx.cpu().long()))
+        np.testing.assert_array_equal(R.recall_at_k(scores, pos, k).cpu().numpy(), z[f"t2i_{k}"])
+        np.testing.assert_array_equal(R.recall_at_k(scores.T, pos.T, k).cpu().numpy(), z[f"i2t_{k}"])
+        # the transposed-view kernel agrees with the row kernel on a materialised transpose
+        _, it = ops.topk_rows(scores.T, k)
+        _, ic = ops.topk_rows(scores.T.contiguous(), k)
+        assert torch.equal(it, ic)
+    np.testing.assert_array_equal(R.batchify(R.recall_at_k, scores, pos, 64, DEV, k=5).numpy(), z["t2i_5"])
+
+
+def test_topk_ties_lowest_index_first():
+    z = load_golden("recall")
+    tie = torch.from_numpy(z["tie_scores"])
+    for k in (1, 5, 10, 17, 32):
+        val, idx = ops.topk_rows(tie.to(DEV), k)
+        ref_v, ref_i = O.topk_rows(tie, k)
+        assert torch.equal(idx.cpu().long(), ref_i) and torch.equal(val.cpu(), ref_v)
+        _, it = ops.topk_rows(tie.t().contiguous().to(DEV).T, k)      # same matrix as a transposed view
+        assert torch.equal(it.cpu().long(), ref_i)
+    # reference topk picks the same SET of values (its tie order is unspecified)
+    ref_vals = tie.gather(1, torch.from_numpy(z["tie_topk_5"]).long()).sort(1)[0]
+    assert torch.equal(ops.topk_rows(tie.to(DEV), 5)[0].cpu().sort(1)[0], ref_vals)
+
+
+def test_topk_full_size_properties():
+    """BASELINE config-2 size (25 014 x 5 000): size-independent checks -- descending order, the k-th
+    value bounds everything not selected, indices unique, both directions."""
+    R_, N = 25014, 5000
+    s = torch.randn(R_, N, generator=g(3)).to(DEV)
+    for view in (s, s.T):
+        val, idx = ops.topk_rows(view, 10)
+        assert (val[:, :-1] >= val[:, 1:]).all()
+        assert torch.equal(view.gather(1, idx.long()), val)
+        assert (idx.long().sort(1)[0].diff(dim=1) > 0).all()
+        cnt_ge = (view >= val[:, -1:]).sum(1)
+        assert (cnt_ge == 10).all()            # continuous scores: no ties
+
+
+def test_gemm_f32_nt():
+    A = torch.randn(300, 512, generator=g(1)); B = torch.randn(77, 512, generator=g(2))
+    Cm = ops.gemm_f32_nt(A.to(DEV), B.to(DEV))
+    assert rel_l2(Cm.cpu(), A @ B.t()) < 1e-6
+
+
+def test_errors_are_loud():
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.ln_fwd(torch.zeros(4, 128), torch.ones(128), torch.zeros(128))
+    with pytest.raises(RuntimeError, match="one stride must be 1"):
+        ops.topk_rows(torch.zeros(8, 16, device=DEV)[:, ::2], 1)
+    with pytest.raises(RuntimeError, match="k"):
+        ops.topk_rows(torch.zeros(8, 16, device=DEV), 40)
