@@ -128,8 +128,9 @@ int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const float* inv,
                           void* stream);
 
 /* ---- AdamW, torch.optim.AdamW(main_TTA.py:271) single-tensor update rule on a flat buffer ---- */
-int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
-                    float beta2, float eps, float wd, int step, void* stream);
+/* hyper-parameters are doubles: torch forms 1-beta, lr*wd, lr/bias_correction in double before the fp32 update */
+int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                    double beta2, double eps, double wd, int step, void* stream);
 
 /* ---- retrieval scoring, evaluation/retrieval.py:280-301 ---- */
 /* Row-wise top-k of a strided f32 matrix (element (r,c) at scores[r*ld_row + c*ld_col]; one of the

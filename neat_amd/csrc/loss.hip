@@ -267,16 +267,18 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     }
 }
 
+// All scalar factors are formed in double on the host exactly like torch.optim.AdamW does in Python
+// (1 - beta2 is 0.001, not 1 - float(0.999)) and rounded to fp32 once.
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float sqrt_bc2) {
+                             float* __restrict__ v, long n, float decay, float omb1, float b2, float omb2, float eps,
+                             float step_size, float sqrt_bc2) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i];
-        float pi = p[i] * (1.0f - lr * wd);
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // lerp_
-        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+        float pi = p[i] * decay;
+        const float mi = m[i] + (gi - m[i]) * omb1;                 // lerp_
+        const float vi = v[i] * b2 + gi * gi * omb2;
         const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-        pi -= (lr / bc1) * (mi / denom);
+        pi -= step_size * (mi / denom);
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
@@ -344,15 +346,16 @@ extern "C" int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const 
     return NEAT_OK;
 }
 
-extern "C" int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                               float eps, float wd, int step, void* stream) {
+extern "C" int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, double lr, double beta1,
+                               double beta2, double eps, double wd, int step, void* stream) {
     NEAT_REQUIRE(p && g && m && v, NEAT_ERR_ARG, "neat_adamw_flat: null pointer");
     NEAT_REQUIRE(n > 0 && step >= 1, NEAT_ERR_SHAPE, "neat_adamw_flat: n=%ld step=%d", n, step);
-    const float bc1 = (float)(1.0 - pow((double)beta1, step));
-    const float sbc2 = (float)sqrt(1.0 - pow((double)beta2, step));
+    const double bc1 = 1.0 - pow(beta1, step);
+    const float sbc2 = (float)sqrt(1.0 - pow(beta2, step));
     long g_ = (n + 255) / 256;
-    hipLaunchKernelGGL(adamw_kernel, dim3((int)(g_ > 1024 ? 1024 : g_)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
-                       beta1, beta2, eps, wd, bc1, sbc2);
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)(g_ > 1024 ? 1024 : g_)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - lr * wd), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), sbc2);
     NEAT_LAUNCH_CHECK("neat_adamw_flat");
     return NEAT_OK;
 }

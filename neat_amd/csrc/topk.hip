@@ -27,23 +27,27 @@ struct TopList {
     // strict '>' keeps the earlier (lower) index ahead on ties
     __device__ __forceinline__ void insert(float x, int idx) {
         if (!(x > v[KP - 1])) return;
+        bool shifting = false;   // once the slot is found everything below moves down by one
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-            if (x > v[j]) {
+            if (shifting || x > v[j]) {
                 const float tv = v[j]; const int ti = i[j];
                 v[j] = x; i[j] = idx;
                 x = tv; idx = ti;
+                shifting = true;
             }
         }
     }
     // general insert for merging lists whose index order is arbitrary
     __device__ __forceinline__ void insert_tie(float x, int idx) {
+        bool shifting = false;
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-            if (x > v[j] || (x == v[j] && idx < i[j])) {
+            if (shifting || x > v[j] || (x == v[j] && idx < i[j])) {
                 const float tv = v[j]; const int ti = i[j];
                 v[j] = x; i[j] = idx;
                 x = tv; idx = ti;
+                shifting = true;
             }
         }
     }

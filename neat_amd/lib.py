@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libneat_hip.so")
 
 EPI_BF16, EPI_BIAS_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_F32 = range(6)
 
-_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/neat_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
@@ -36,7 +36,7 @@ SIGNATURES = {
     "neat_coarse_align": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "neat_loss_ws_floats": (_L, [_I, _I]),
     "neat_tta_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "neat_adamw_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "neat_adamw_flat": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _I, _P]),
     "neat_topk_ws_bytes": (_L, [_I, _I, _I]),
     "neat_topk_rows": (_I, [_P, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
     "neat_recall_from_topk": (_I, [_P, _P, _L, _L, _I, _I, _I, _P, _P]),

@@ -95,12 +95,10 @@ class _EncodeText(torch.autograd.Function):
     hand-written HIP backward that deposits d(gamma), d(beta) into the LN parameters' .grad."""
 
     @staticmethod
-    def forward(ctx, model, tokens, normalize, *ln_params):
+    def forward(ctx, model, tokens, normalize, save, *ln_params):
         tower = model._text_tower()
-        save = any(p.requires_grad for p in ln_params) and torch.is_grad_enabled()
         feat, tctx = tower.forward(tokens, normalize, save)
         ctx.tower, ctx.tctx, ctx.model = tower, tctx, model
-        ctx.mark_non_differentiable()
         return feat
 
     @staticmethod
@@ -115,7 +113,7 @@ class _EncodeText(torch.autograd.Function):
         out = []
         for g in grads:
             out += [g["ln1_w"], g["ln1_b"], g["ln2_w"], g["ln2_b"]]
-        return (None, None, None, *out)
+        return (None, None, None, None, *out)
 
 
 class CLIP(nn.Module):
@@ -219,7 +217,9 @@ class CLIP(nn.Module):
             raise RuntimeError("encode_text: expected a GPU tensor")
         if text.dtype != torch.int64:
             text = text.long()
-        return _EncodeText.apply(self, text, normalize, *self._text_ln_params())
+        ln = self._text_ln_params()
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in ln)   # activations kept only if needed
+        return _EncodeText.apply(self, text, normalize, save, *ln)
 
     def get_logits(self, image, text):
         image_features = self.encode_image(image, normalize=True)
