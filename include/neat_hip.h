@@ -61,9 +61,16 @@ int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, float* dgamma
                          int accumulate, void* stream);
 
 /* ---- bf16 MFMA GEMM: nn.Linear / MHA projections, open_clip/transformer.py:209-213,227-229 ---- */
-/* out[M,N] = epilogue(A[M,K] * W[N,K]^T).  A, W bf16, K-contiguous; K % 64 == 0, N % 16 == 0.
- * bias f32 [N]; res f32 [M,N] (may alias out0); aux bf16 [M,N].  Unused pointers may be NULL. */
-int neat_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, const float* res,
+/* Frozen weights are packed ONCE into MFMA-fragment order (bf16).  Logical matrix Wl[N,K]:
+ *   transposed == 0: Wl = src, row-major f32 [N,K]           (forward: nn.Linear.weight [out,in])
+ *   transposed != 0: Wl[n][k] = src[k*N + n], src f32 [K,N]  (data gradient: dX = dY . W needs W^T)
+ * dst holds N*K bf16: dst[((nt*(K/32)+ks)*64+lane)*8+j] = Wl[nt*16+(lane&15)][ks*32+(lane>>4)*8+j].
+ * N % 16 == 0, K % 32 == 0. */
+int neat_pack_weight_bf16(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream);
+/* out[M,N] = epilogue(A[M,K] * Wl[N,K]^T).  A bf16 row-major (K-contiguous); Wp = packed Wl (above);
+ * K % 128 == 0, N % 16 == 0.  bias f32 [N]; res f32 [M,N] (may alias out0); aux bf16 [>=M,N].
+ * Unused pointers may be NULL. */
+int neat_gemm_bf16(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                    const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                    void* stream);
 
@@ -147,7 +154,7 @@ int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int
 
 /* f32 -> bf16 cast (weights at load time, n elements) */
 int neat_cast_bf16(const float* src, uint16_t* dst, long n, void* stream);
-/* f32 [R,C] -> bf16 [C,R] transpose-cast (dgrad uses W^T stored K-contiguous) */
+/* f32 [R,C] -> bf16 [C,R] transpose-cast */
 int neat_transpose_cast_bf16(const float* src, uint16_t* dst, int R, int C, void* stream);
 
 #ifdef __cplusplus

@@ -1,181 +1,337 @@
-// bf16 MFMA GEMM with fused epilogues for the encoder linears (MFMA-bound kernels).
+// bf16 MFMA GEMM with fused epilogues for the encoder linears.
 // Replaces nn.Linear / nn.MultiheadAttention projections (reference open_clip/transformer.py:209-213,
 // 227-229) and their data-gradient GEMMs (weights are frozen: there is no wgrad on this path).
 //
-//   out[M,N] = epilogue( A[M,K] . W[N,K]^T )      A = activations, W = weights, both K-contiguous
+//   out[M,N] = epilogue( A[M,K] . W[N,K]^T )      A = activations (row-major), W = weights (packed)
 //
-// CDNA4 mapping
-//  * 128x128 block tile, BK = 64, 4 wavefronts (2x2), each owning a 64x64 sub-tile as 4x4
-//    v_mfma_f32_16x16x32_bf16 accumulators.
-//  * W is the MFMA *A* operand and the activations the *B* operand, so an accumulator register
-//    quad holds 4 CONSECUTIVE output columns n for one row m: bias / residual / saved-activation
-//    loads and the output stores of the epilogue are 8-16 B per lane.
-//  * global -> LDS by global_load_lds_dwordx4 (no VGPR round trip), double buffered; the LDS image
-//    is lane-linear (1 KiB per wave-instruction), the bank-conflict XOR swizzle is applied to the
-//    per-lane SOURCE address and to the ds_read_b128 address (chunk ^= (row>>1)&7 on 128-B rows).
-//  * 1-D grid remapped so that the 8 XCDs each walk a contiguous range of tiles (tiles that share
-//    an activation row-panel hit the same L2).
-//  * rows >= M / weight rows >= N are clamped on load and masked on store: no padding contract.
+// Shape regime of this path: M = 4*B*77 ~ 8e4 rows, K = 512..2048, N = 512..2048.  At these sizes the
+// activation/output streams are as expensive as the MFMAs (arithmetic intensity sits at the HBM/MFMA
+// ridge), so the kernel is built around the ACTIVATION stream ("activation-stationary"):
+//
+//  * work unit = 128 rows x 256 columns; persistent grid of TWO 512-thread workgroups per CU (16 waves,
+//    4 per SIMD, <= 128 VGPRs each), units dealt round-robin.  Two independent workgroups per CU drift out
+//    of phase, so one's epilogue (a per-CU store stream of ~10 B/clk) overlaps the other's MFMAs;
+//  * the unit's 128-row sub-panel streams through LDS in [128 x 128-k] pieces, double buffered
+//    (2 x 32 KiB), filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).  The LDS image is
+//    lane-linear; the bank-conflict XOR swizzle (16-B chunk ^= row & 15) is applied to the per-lane SOURCE
+//    address and to the ds_read_b128 address.  ONE raw barrier per piece, with no vmcnt drain, so epilogue
+//    stores keep flowing behind it;
+//  * the frozen weights are pre-packed once (neat_pack_weight_bf16) in MFMA-fragment order, so a wave
+//    loads each W fragment as one contiguous, fully coalesced 1-KiB global read (L2-resident: |W| <= 2 MB)
+//    straight into VGPRs -- no LDS traffic, no barrier, reused by the 8 row-tiles of the sub-panel;
+//  * W is the MFMA *A* operand and the activations the *B* operand, so an accumulator quad holds 4
+//    CONSECUTIVE output columns n of one row m: bias / residual / saved-activation loads and the output
+//    stores of the epilogue are 8-16 B per lane, and a wave (64 columns) writes whole 128-B lines;
+//  * the LDS-DMA fills are issued from inline asm by a rotating half of the waves (one per SIMD) so that
+//    the in-order vmcnt queue of the OTHER wave on each SIMD only ever holds L2-latency weight loads:
+//    while a filling wave waits out its HBM-latency fills, its SIMD partner keeps the MFMA pipe busy;
+//  * epilogue: each 16 x 32 accumulator tile is transposed through a wave-private LDS slab so that every
+//    global access (bias, residual, saved activation, output) is a whole 128-B line.
+//
+// Rows >= M are clamped on load and masked on store; N needs % 16, K needs % 128.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace neat {
 
-constexpr int G_BM = 128, G_BN = 128, G_BK = 64;
-constexpr int G_THREADS = 256;
-constexpr int G_TILE_BYTES = G_BM * G_BK * 2;            // 16 KiB per operand tile
-constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;          // A + W
-constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;           // double buffer = 64 KiB
+constexpr int P_THREADS = 512;
+constexpr int P_WAVES = 8;                // per workgroup; two workgroups per CU -> 4 waves per SIMD
+constexpr int P_NI = 2;                   // 16-column tiles per wave: a unit is 128 rows x 256 columns
+constexpr int P_BKH = 128;                // k extent of one LDS piece
+// LDS: two [128 x BKH] bf16 pieces + one epilogue slab (16 rows x NI*16 fp32) per wave
+constexpr int lds_piece_bytes(int bkh) { return 128 * bkh * 2; }
+constexpr int lds_total_bytes(int bkh, int ni) { return 2 * lds_piece_bytes(bkh) + P_WAVES * ni * 1024; }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+// one LDS-DMA wave-instruction: 64 lanes x 16 B -> lds_dst .. lds_dst+1023 (lane-linear)
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
 
-// Stage one 128x64 bf16 tile: 1024 16-B chunks, 4 per thread.  LDS chunk q=(row r=q>>3, c=q&7)
-// receives global chunk c ^ ((r>>1)&7) of row r.
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long ld, int row0, int nrows_total,
-                                           int k0, char* lds_tile, int wave, int lane) {
+// One LDS piece: ksteps x (NI weight fragments from global, 8 activation fragments from LDS, NI*8 MFMAs),
+// straight-line (no per-tile branches: they would serialise every ds_read behind the previous MFMAs).
+template <int NI, int BKH>
+__device__ __forceinline__ void piece_mma(f32x4 (&acc)[NI][8], const uint4* __restrict__ wp, const long (&woff)[NI],
+                                          const char* abase, int fr, int fq) {
+    constexpr int ksteps = BKH >> 5;
+    constexpr int rowbytes = (BKH >> 3) * 16;
+    uint4 wn[NI];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = p * 256 + wave * 64 + lane;
-        const int r = q >> 3;
-        const int c = (q & 7) ^ ((r >> 1) & 7);
-        int gr = row0 + r;
-        gr = gr < nrows_total ? gr : nrows_total - 1;
-        const bf16_t* g = src + (long)gr * ld + k0 + c * 8;
-        char* l = lds_tile + (p * 256 + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
-        __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
+    for (int i = 0; i < NI; ++i) wn[i] = wp[woff[i]];
+#pragma unroll
+    for (int kk = 0; kk < ksteps; ++kk) {
+        bf16x8 wf[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(bf16x8, wn[i]);
+        if (kk + 1 < ksteps) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wn[i] = wp[woff[i] + (kk + 1) * 64];
+        }
+        const int coff = ((kk * 4 + fq) ^ fr) * 16;
+#pragma unroll
+        for (int tg = 0; tg < 8; tg += 4) {      // 4 row tiles at a time keeps the fragment registers at 16
+            bf16x8 af[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                af[t] = *reinterpret_cast<const bf16x8*>(abase + (tg + t) * 16 * rowbytes + coff);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#ifndef NEAT_ABL_NOMFMA
+                    acc[i][tg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[t], acc[i][tg + t], 0, 0, 0);
+#else
+                    asm volatile("" :: "v"(wf[i]), "v"(af[t]));
+#endif
+        }
     }
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
-    const int c = chunk ^ ((row >> 1) & 7);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + c * 16);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(G_THREADS) void gemm_bf16_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    const float* res, const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K, int ntm,
-    int ntn) {
+// Work unit = (128-row sub-panel, column block of 8 waves x NI x 16 columns); units are dealt round-robin to
+// the persistent workgroups.  Each unit streams its sub-panel through LDS in K/BKH pieces.
+template <int EPI, int BKH, int NI, int OCC>
+__global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
+    const bf16_t* __restrict__ A, const uint4* __restrict__ Wp, const float* __restrict__ bias, const float* res,
+    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int ksteps = BKH >> 5;                 // MFMA k-steps per piece (4 or 8)
+    constexpr int cpr = BKH >> 3;                    // 16-B chunks per LDS row (16 or 32)
+    constexpr int rpi = 64 / cpr;                    // rows per LDS-DMA wave-instruction (4 or 2)
+    constexpr int ninstr = 128 * cpr / 64;           // wave-instructions per piece
+    constexpr int CB = P_WAVES * NI * 16;            // columns per unit
+    constexpr int P_BUF_BYTES = lds_piece_bytes(BKH);
+    constexpr int P_LDS_BYTES = 2 * P_BUF_BYTES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // XCD-aware bijective remap of the 1-D grid (blocks b and b+8 share an XCD)
-    const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int tm = tile / ntn, tn = tile - tm * ntn;
-    const int m0 = tm * G_BM, n0 = tn * G_BN;
-
-    const int wm = wave & 1, wn = wave >> 1;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / G_BK;
-    stage_tile(A, K, m0, M, 0, lds, wave, lane);
-    stage_tile(W, K, n0, N, 0, lds + G_TILE_BYTES, wave, lane);
-    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the stage
-
     const int fr = lane & 15, fq = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        char* cur = lds + (t & 1) * G_STAGE_BYTES;
-        if (t + 1 < nk) {
-            char* nxt = lds + ((t + 1) & 1) * G_STAGE_BYTES;
-            stage_tile(A, K, m0, M, (t + 1) * G_BK, nxt, wave, lane);
-            stage_tile(W, K, n0, N, (t + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
-        }
-        const char* At = cur;
-        const char* Wt = cur + G_TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[4], xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = lds_frag(Wt, wn * 64 + i * 16 + fr, kk * 4 + fq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xf[j] = lds_frag(At, wm * 64 + j * 16 + fr, kk * 4 + fq);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;  // LDS byte address
 
-    // epilogue: lane holds, for row m, the 4 consecutive columns n .. n+3
+    const int nsub = (M + 127) >> 7;
+    const int ncb = (N + CB - 1) / CB;
+    const int nunits = nsub * ncb;
+    const int G = gridDim.x;
+    const int myunits = (nunits - (int)blockIdx.x + G - 1) / G;   // units blockIdx.x, +G, +2G, ...
+    if (myunits <= 0) return;                                     // uniform
+    const int nkh = K / BKH;                         // pieces along K
+    const int ksK = K >> 5;                          // k-steps in the whole K (packed-W stride)
+    const int J = myunits * nkh;                     // pieces this workgroup consumes
+
+    auto issue_piece = [&](int j) {
+        const int u = blockIdx.x + (j / nkh) * G;
+        const int kh = j % nkh;
+        const int row0 = (u / ncb) << 7;
+        const uint32_t buf = lds_base + (j & 1) * P_BUF_BYTES;
+        const bf16_t* src = A + kh * BKH;
+        for (int q = (wave & 3); q < ninstr; q += 4) {
+            const int row = q * rpi + lane / cpr;                  // row inside the piece
+            const int c = (lane % cpr) ^ (row & 15);
+            int gr = row0 + row;
+            gr = gr < M ? gr : M - 1;
+            glds16(src + (long)gr * K + c * 8, buf + q * 1024);
+        }
+    };
+
+    if ((wave >> 2) == 0) issue_piece(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    f32x4 acc[NI][8];
+    for (int j = 0; j < J; ++j) {
+        const int u = blockIdx.x + (j / nkh) * G;
+        const int kh = j % nkh;
+        const int sub = u / ncb, cb = u - sub * ncb;
+
+        // piece j is in LDS (its fillers waited vmcnt(0) before arriving here) and nobody reads buffer
+        // (j+1)&1 any more.  Raw barrier: no vmcnt(0), so epilogue stores keep draining behind it.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (j + 1 < J && (wave >> 2) == ((j + 1) & 1)) issue_piece(j + 1);
+
+        if (kh == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= M) continue;
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
-            if (n >= N) continue;
-            const long o = (long)m * N + n;
-            f32x4 v = acc[i][j];
-            if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int nt0 = (cb * CB >> 4) + wave * NI;                 // first of this wave's NI column tiles
+        const int nvalid = (N >> 4) - nt0;                          // how many of them exist (<=0: idle)
+        if (nvalid > 0) {
+            const char* buf = lds + (j & 1) * P_BUF_BYTES;
+            const uint4* wp = Wp + ((long)nt0 * ksK + (long)kh * ksteps) * 64 + lane;
+            long woff[NI];                                          // missing column tiles re-read the last valid one
+#pragma unroll
+            for (int i = 0; i < NI; ++i) woff[i] = (long)(i < nvalid ? i : nvalid - 1) * ksK * 64;
+            piece_mma<NI, BKH>(acc, wp, woff, buf + fr * (cpr * 16), fr, fq);
+            // the fills this wave issued for piece j+1 have had the whole k-loop to land; retire them BEFORE
+            // the epilogue stores so that the next barrier needs no vmcnt wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NEAT_ABL_NOSTORE
+            if (kh == nkh - 1) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(acc[i][t]));
             }
-            if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
-                *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-            } else if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                const float4 r = *reinterpret_cast<const float4*>(res + o);
-                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v[0] + r.x, v[1] + r.y, v[2] + r.z, v[3] + r.w);
-            } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
-                // the saved pre-activation is the bf16-rounded value; GELU is applied to the same
-                // rounded value so that forward and backward see one h
-                const uint2 hp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                if (out0) *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = hp;
-                const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
-                const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
-                *reinterpret_cast<uint2*>((bf16_t*)out1 + o) =
-                    make_uint2(pack2bf(quick_gelu(h0), quick_gelu(h1)), pack2bf(quick_gelu(h2), quick_gelu(h3)));
-            } else if constexpr (EPI == NEAT_EPI_GELU_BWD) {
-                const uint2 hp = *reinterpret_cast<const uint2*>(aux + o);
-                const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
-                const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
-                *reinterpret_cast<uint2*>((bf16_t*)out0 + o) =
-                    make_uint2(pack2bf(v[0] * quick_gelu_grad(h0), v[1] * quick_gelu_grad(h1)),
-                               pack2bf(v[2] * quick_gelu_grad(h2), v[3] * quick_gelu_grad(h3)));
-            } else {  // NEAT_EPI_F32
-                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (kh == nkh - 1 && M < 0) {
+#else
+            if (kh == nkh - 1) {
+#endif
+                // Epilogue.  The accumulator holds 4 consecutive columns per lane but 16 different ROWS per
+                // wave-instruction (32-B requests).  Each 16 x (NI*16) tile is therefore transposed through a
+                // wave-private 4-KiB LDS slab (XOR-swizzled 16-B chunks, conflict-free both ways) so that
+                // consecutive lanes cover one row: every global access below is a whole 128/256-B line.
+                char* stg = lds + P_LDS_BYTES + wave * (NI * 1024);
+                constexpr int CPW = NI * 4;                             // 16-B fp32 chunks per row of the slab
+                constexpr int RPI = 64 / CPW;                           // rows per read instruction
+                const int ncols = nvalid < NI ? nvalid * 16 : NI * 16;  // valid columns of this wave's slab
+                const int cl = lane % CPW, rq = lane / CPW;
+                const int n = nt0 * 16 + cl * 4;
+                const bool col_ok = cl * 4 < ncols;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU) {
+                    if (col_ok) bv = *reinterpret_cast<const float4*>(bias + n);
+                }
+                const int rowm0 = sub << 7;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        *reinterpret_cast<f32x4*>(stg + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
+#pragma unroll
+                    for (int r = 0; r < 16 / RPI; ++r) {
+                        const int row = r * RPI + rq;
+                        const float4 a4 = *reinterpret_cast<const float4*>(stg + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
+                        const int m = rowm0 + t * 16 + row;
+                        if (m >= M || !col_ok) continue;
+                        const long o = (long)m * N + n;
+                        float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+                        if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
+                            *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+                        } else if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                            const float4 rr = *reinterpret_cast<const float4*>(res + o);
+                            *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
+                        } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                            // the saved pre-activation is the bf16-rounded value; GELU is applied to the same
+                            // rounded value so that forward and backward see one h
+                            const uint2 hp = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+                            if (out0) *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = hp;
+                            const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
+                            const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
+                            *reinterpret_cast<uint2*>((bf16_t*)out1 + o) = make_uint2(
+                                pack2bf(quick_gelu(h0), quick_gelu(h1)), pack2bf(quick_gelu(h2), quick_gelu(h3)));
+                        } else if constexpr (EPI == NEAT_EPI_GELU_BWD) {
+                            const uint2 hp = *reinterpret_cast<const uint2*>(aux + o);
+                            const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
+                            const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
+                            *reinterpret_cast<uint2*>((bf16_t*)out0 + o) =
+                                make_uint2(pack2bf(v0 * quick_gelu_grad(h0), v1 * quick_gelu_grad(h1)),
+                                           pack2bf(v2 * quick_gelu_grad(h2), v3 * quick_gelu_grad(h3)));
+                        } else {  // NEAT_EPI_F32
+                            *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0, v1, v2, v3);
+                        }
+                    }
+                }
             }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
 
-template <int EPI>
-static int launch_gemm(const uint16_t* A, const uint16_t* W, const float* bias, const float* res,
-                       const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
-    const int ntm = cdiv(M, G_BM), ntn = cdiv(N, G_BN);
-    static bool attr_set = false;  // per-template-instance: allow 64 KiB dynamic LDS
+// f32 weights -> bf16 in MFMA-fragment order.  Logical matrix Wl[n][k] (N x K): Wl = src (row-major [N,K])
+// or, with transposed != 0, Wl[n][k] = src[k*N + n] (src row-major [K,N]: the dgrad operand W^T).
+// dst[((nt*(K/32) + ks)*64 + lane)*8 + j] = Wl[nt*16 + (lane&15)][ks*32 + (lane>>4)*8 + j]
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int K,
+                                   int transposed) {
+    const long total = (long)(N / 16) * (K / 32) * 64;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(u & 63);
+        const long tile = u >> 6;
+        const int ks = (int)(tile % (K / 32));
+        const int nt = (int)(tile / (K / 32));
+        const int n = nt * 16 + (lane & 15);
+        const int k0 = ks * 32 + (lane >> 4) * 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 2 * j;
+            const float a = transposed ? src[(long)k * N + n] : src[(long)n * K + k];
+            const float b = transposed ? src[(long)(k + 1) * N + n] : src[(long)n * K + k + 1];
+            w[j] = pack2bf(a, b);
+        }
+        reinterpret_cast<uint4*>(dst)[u] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+static int g_num_cu = 0;
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_num_cu = n;
+    }
+    return g_num_cu;
+}
+
+template <int EPI, int BKH, int NI, int OCC>
+static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
+                         const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int grid, hipStream_t s) {
+    constexpr int ldsb = lds_total_bytes(BKH, NI);
+    static bool attr_set = false;  // per-template-instance: allow > 64 KiB dynamic LDS
     if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES),
+        int rc = check_hip(hipFuncSetAttribute((const void*)gemm_panel_kernel<EPI, BKH, NI, OCC>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsb),
                            "hipFuncSetAttribute(gemm)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(ntm * ntn), dim3(G_THREADS), G_LDS_BYTES, s, A, W, bias, res,
-                       aux, out0, out1, M, N, K, ntm, ntn);
+    hipLaunchKernelGGL((gemm_panel_kernel<EPI, BKH, NI, OCC>), dim3(grid), dim3(P_THREADS), ldsb, s, A,
+                       reinterpret_cast<const uint4*>(Wp), bias, res, aux, out0, out1, M, N, K);
     NEAT_LAUNCH_CHECK("neat_gemm_bf16");
     return NEAT_OK;
+}
+
+template <int EPI>
+static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
+                       const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
+    const int cus = num_cus();
+    const long units = (long)cdiv(M, 128) * cdiv(N, P_WAVES * P_NI * 16);
+    const int grid = (int)(units < 2 * cus ? units : 2 * cus);   // persistent: two workgroups per CU
+    return launch_gemm_c<EPI, P_BKH, P_NI, 2>(A, Wp, bias, res, aux, out0, out1, M, N, K, grid, s);
 }
 
 }  // namespace neat
 
 using namespace neat;
 
+extern "C" long neat_packed_weight_elems(int N, int K) { return (long)N * K; }
+
+extern "C" int neat_pack_weight_bf16(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream) {
+    NEAT_REQUIRE(src && dst, NEAT_ERR_ARG, "neat_pack_weight_bf16: null pointer");
+    NEAT_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, NEAT_ERR_SHAPE,
+                 "neat_pack_weight_bf16: N=%d K=%d (need N %% 16 == 0, K %% 32 == 0)", N, K);
+    const long total = (long)(N / 16) * (K / 32) * 64;
+    long g = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                       K, transposed);
+    NEAT_LAUNCH_CHECK("neat_pack_weight_bf16");
+    return NEAT_OK;
+}
+
 extern "C" int neat_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, const float* res,
                               const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                               void* stream) {
     NEAT_REQUIRE(A && W, NEAT_ERR_ARG, "neat_gemm_bf16: null operand");
-    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0 && N % 16 == 0, NEAT_ERR_SHAPE,
-                 "neat_gemm_bf16: M=%d N=%d K=%d unsupported (need K %% 64 == 0, N %% 16 == 0)", M, N, K);
+    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 16 == 0, NEAT_ERR_SHAPE,
+                 "neat_gemm_bf16: M=%d N=%d K=%d unsupported (need K %% 128 == 0, N %% 16 == 0)", M, N, K);
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case NEAT_EPI_BF16:

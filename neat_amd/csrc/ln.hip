@@ -14,7 +14,6 @@ namespace neat {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / WAVE;
-constexpr int LN_MAXCH = 4;  // cols <= 4*64*4 = 1024
 
 template <int NCH>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x,
@@ -175,14 +174,22 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     for (int c = threadIdx.x; c < 2 * cols; c += LN_THREADS) dst[c] = red[c];
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int cols, float* dgamma,
-                                       float* dbeta, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * cols) return;
+// 64 columns x 4 row-slices per block: coalesced 256-B reads, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int cols,
+                                                              float* dgamma, float* dbeta, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * cols + c];
-    float* dst = (c < cols) ? dgamma + c : dbeta + (c - cols);
-    *dst = accumulate ? (*dst + s) : s;
+    if (c < 2 * cols)
+        for (int b = slice; b < nblk; b += 4) s += partial[(long)b * 2 * cols + c];
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && c < 2 * cols) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* dst = (c < cols) ? dgamma + c : dbeta + (c - cols);
+        *dst = accumulate ? (*dst + s) : s;
+    }
 }
 
 static int ln_grid(int rows) {
@@ -214,8 +221,10 @@ extern "C" int neat_ln_fwd(const float* x, const float* gamma, const float* beta
 }
 
 extern "C" int neat_ln_bwd_blocks(int rows) {
+    // every block leaves one partial row pair behind, so keep the grid at ~2 blocks per CU: the streaming
+    // part stays HBM-bound (8 waves/CU x 16 B loads) and the finalize pass reads only 512 partial rows
     int g = cdiv(rows, LN_WAVES * 16);
-    return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    return g < 1 ? 1 : (g > 512 ? 512 : g);
 }
 
 extern "C" int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
@@ -242,7 +251,7 @@ extern "C" int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, fl
                                     int accumulate, void* stream) {
     NEAT_REQUIRE(partial && dgamma && dbeta, NEAT_ERR_ARG, "neat_ln_bwd_finalize: null pointer");
     NEAT_REQUIRE(nblk > 0 && cols > 0, NEAT_ERR_SHAPE, "neat_ln_bwd_finalize: bad shape");
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(2 * cols, 128)), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(2 * cols, 64)), dim3(256), 0, (hipStream_t)stream,
                        partial, nblk, cols, dgamma, dbeta, accumulate);
     NEAT_LAUNCH_CHECK("neat_ln_bwd_finalize");
     return NEAT_OK;

@@ -6,8 +6,8 @@ Data layout in HBM (row-major, rows = tokens of all sequences back to back):
   LN output / attn output  bf16 [M, C]      GEMM A operands (temporaries)
   qkv                      bf16 [M, 3C]     saved per layer (attention backward recomputes P from lse)
   MLP pre-activation h     bf16 [M, 4C]     saved per layer (QuickGELU')
-  weights                  bf16 [N, K] K-contiguous, plus the transposed copy [K, N] for the
-                           data-gradient GEMMs (weights are frozen: no wgrad, copies made once)
+  weights                  bf16, packed once in MFMA-fragment order (W for forward, W^T for the
+                           data-gradient GEMMs; weights are frozen: no wgrad)
   LN gamma/beta, biases, statistics, features, loss, optimizer state: fp32.
 
 Reference call sites: open_clip/model.py:265-286 (encode_image / encode_text),
@@ -32,8 +32,10 @@ class BlockWeights:
         self.ln2_w, self.ln2_b = blk.ln_2.weight, blk.ln_2.bias
         mats = dict(qkv=blk.attn.in_proj_weight, o=blk.attn.out_proj.weight, fc=blk.mlp.c_fc.weight,
                     proj=blk.mlp.c_proj.weight)
-        self.w = {k: ops.cast_bf16(v.detach().contiguous()) for k, v in mats.items()}
-        self.wT = {k: ops.transpose_cast_bf16(v.detach().contiguous()) for k, v in mats.items()} if need_bwd else None
+        # packed once: weights are frozen during TTA (only LN gamma/beta adapt)
+        self.w = {k: ops.pack_weight(v.detach().contiguous()) for k, v in mats.items()}
+        self.wT = {k: ops.pack_weight(v.detach().contiguous(), transposed=True) for k, v in mats.items()} \
+            if need_bwd else None
         self.b = dict(qkv=blk.attn.in_proj_bias.detach(), o=blk.attn.out_proj.bias.detach(),
                       fc=blk.mlp.c_fc.bias.detach(), proj=blk.mlp.c_proj.bias.detach())
 
@@ -124,11 +126,11 @@ class VisionTower:
         self.patch = v.conv1.weight.shape[-1]
         self.D = v.proj.shape[1]
         K = 3 * self.patch * self.patch
-        self.Kpad = (K + 63) // 64 * 64
+        self.Kpad = (K + 127) // 128 * 128
         w = v.conv1.weight.detach().reshape(self.C, K)
         if self.Kpad != K:
             w = torch.nn.functional.pad(w, (0, self.Kpad - K))
-        self.w_patch = ops.cast_bf16(w.contiguous())
+        self.w_patch = ops.pack_weight(w.contiguous())
         self.cls = v.class_embedding.detach()
         self.pos = v.positional_embedding.detach()
         self.lnpre = (v.ln_pre.weight.detach(), v.ln_pre.bias.detach())

@@ -104,14 +104,34 @@ def ln_bwd(dy, x, gamma, mean, rstd, dres=None, want_f32=True, want_bf16=True, d
 
 
 # ---- GEMM ----
-def gemm(A, W, epilogue, bias=None, res=None, aux=None, out0=None, out1=None):
-    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); allocates outputs that are not passed in."""
+class PackedWeight:
+    """A frozen weight matrix in the kernel's MFMA-fragment order (see include/neat_hip.h).
+    ``N`` / ``K`` are the LOGICAL dims of out[M,N] = A[M,K] @ Wl[N,K]^T."""
+
+    __slots__ = ("data", "N", "K")
+
+    def __init__(self, data, N, K):
+        self.data, self.N, self.K = data, N, K
+
+
+def pack_weight(w, transposed=False) -> PackedWeight:
+    """w fp32 [N,K] (transposed=False) or fp32 [K,N] whose transpose is the logical matrix (dgrad)."""
+    if w.dim() != 2:
+        raise RuntimeError("pack_weight: expected a 2-D weight")
+    N, K = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    dst = torch.empty(N * K, dtype=bf16, device=w.device)
+    lib.call("neat_pack_weight_bf16", _p(w, f32, "w"), _p(dst), N, K, int(transposed), _stream())
+    return PackedWeight(dst, N, K)
+
+
+def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None, out1=None):
+    """out[M,N] = epilogue(A[M,K] @ Wl[N,K]^T); allocates outputs that are not passed in."""
     M, K = A.shape
-    N = W.shape[0]
-    if W.shape[1] != K:
-        raise RuntimeError(f"gemm: K mismatch {A.shape} x {W.shape}")
+    N = W.N
+    if W.K != K:
+        raise RuntimeError(f"gemm: K mismatch {tuple(A.shape)} x packed [{W.N},{W.K}]")
     dev = A.device
-    if out0 is None and not (epilogue == lib.EPI_BIAS_GELU and False):
+    if out0 is None:
         out0 = torch.empty(M, N, dtype=f32 if epilogue in (lib.EPI_BIAS_RES_F32, lib.EPI_F32) else bf16, device=dev)
     if epilogue == lib.EPI_BIAS_GELU and out1 is None:
         out1 = torch.empty(M, N, dtype=bf16, device=dev)
@@ -124,14 +144,14 @@ def gemm(A, W, epilogue, bias=None, res=None, aux=None, out0=None, out1=None):
         raise RuntimeError("gemm: residual shape mismatch")
     if aux is not None and (aux.dtype != bf16 or aux.shape[1] != N or aux.shape[0] < M):
         raise RuntimeError("gemm: aux shape/dtype mismatch")
+    args = (_p(A, bf16, "A"), _p(W.data, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0), _p(out1), M, N, K, epilogue,
+            _stream())
     t = KERNEL_TIMER
     if t is not None and t.match("gemm", epilogue, M, N, K):
         with t.region(M, N, K):
-            lib.call("neat_gemm_bf16", _p(A, bf16, "A"), _p(W, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0),
-                     _p(out1), M, N, K, epilogue, _stream())
-        return out0, out1
-    lib.call("neat_gemm_bf16", _p(A, bf16, "A"), _p(W, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0), _p(out1),
-             M, N, K, epilogue, _stream())
+            lib.call("neat_gemm_bf16", *args)
+    else:
+        lib.call("neat_gemm_bf16", *args)
     return out0, out1
 
 

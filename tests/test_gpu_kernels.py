@@ -71,7 +71,8 @@ def test_ln_is_deterministic():
 
 
 # ------------------------------------------------------------------ GEMM
-SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 64), (512, 512, 2048), (77, 1536, 768)]
+SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 128), (512, 512, 2048), (77, 1536, 768),
+          (5000, 528, 384), (40000, 512, 512)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -81,7 +82,7 @@ def test_gemm_epilogues(M, N, K):
     bias = torch.randn(N, generator=g(3)) * 0.1
     res = torch.randn(M, N, generator=g(4))
     ref = A.float() @ W.float().t()
-    Ad, Wd, bd, rd = A.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
+    Ad, Wd, bd, rd = A.to(DEV), ops.pack_weight(W.float().to(DEV)), bias.to(DEV), res.to(DEV)
     tol = 6e-3
     o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16)
     assert rel_l2(o.float().cpu(), ref) < tol
@@ -109,19 +110,24 @@ def test_gemm_exact_small_integers():
     K = 256
     A = torch.eye(M, K)
     W = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 7) % 61 - 30.0
-    o, _ = ops.gemm(bf(A).to(DEV), bf(W).to(DEV), lib.EPI_F32)
+    o, _ = ops.gemm(bf(A).to(DEV), ops.pack_weight(W.to(DEV)), lib.EPI_F32)
     assert torch.equal(o.cpu(), (A @ W.t()))
-    A2 = torch.randint(-4, 5, (333, 192), generator=g(1)).float()
-    W2 = torch.randint(-4, 5, (80, 192), generator=g(2)).float()
-    o, _ = ops.gemm(bf(A2).to(DEV), bf(W2).to(DEV), lib.EPI_F32)
+    A2 = torch.randint(-4, 5, (333, 256), generator=g(1)).float()
+    W2 = torch.randint(-4, 5, (80, 256), generator=g(2)).float()
+    o, _ = ops.gemm(bf(A2).to(DEV), ops.pack_weight(W2.to(DEV)), lib.EPI_F32)
+    assert torch.equal(o.cpu(), A2 @ W2.t())
+    # the data-gradient operand: logical matrix = transpose of the stored [K_l, N_l] weight
+    o, _ = ops.gemm(bf(A2).to(DEV), ops.pack_weight(W2.t().contiguous().to(DEV), transposed=True), lib.EPI_F32)
     assert torch.equal(o.cpu(), A2 @ W2.t())
 
 
 def test_gemm_rejects_bad_shapes():
-    A = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
-    W = torch.zeros(16, 100, dtype=torch.bfloat16, device=DEV)
+    A = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
+    W = ops.pack_weight(torch.zeros(16, 96, device=DEV))
     with pytest.raises(RuntimeError, match="K"):
         ops.gemm(A, W, lib.EPI_BF16)
+    with pytest.raises(RuntimeError, match="K mismatch"):
+        ops.gemm(torch.zeros(8, 128, dtype=torch.bfloat16, device=DEV), W, lib.EPI_BF16)
 
 
 # ------------------------------------------------------------------ attention
