@@ -152,53 +152,95 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const bf16_t* __re
     }
 }
 
+// ---- backward: one 192-thread workgroup (3 wavefronts) per (sequence, head) ----
+// Q, K, V, dO tiles are staged ONCE, row-major, into LDS with coalesced 16-B loads.  Every MFMA operand
+// then comes from LDS: k-contiguous fragments by ds_read_b128, and the fragments of products that sum
+// over the sequence index (dQ = dS.K, dK = dS^T.Q, dV = P^T.dO) by the gfx950 transposing read
+// ds_read_b64_tr_b16 on the same row-major image -- no transposed copies, no scalar LDS stores.
+// The causal work (tile pairs) is dealt to the three waves in snake order, which balances it exactly for
+// L = 77 (5 tiles: 5+5+5 tile pairs).
+constexpr int AB_WAVES = 3;
+constexpr int AB_THREADS = AB_WAVES * 64;
+constexpr int AB_PITCH = 72;   // bf16 elements per LDS row (64 + 8 pad: 144 B, 16-B aligned, conflict-free rows)
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 lds_rowfrag(const bf16_t* T, int row, int ks, int fq) {
+    return *reinterpret_cast<const bf16x8*>(T + row * AB_PITCH + ks * 32 + fq * 8);
+}
+
+// fragment with the SUMMED index on the tile rows: element j<4 = T[ta*16+4fq+j][d], j>=4 = T[tb*16+4fq+j-4][d],
+// d = dt*16 + fr.  Lane 4q+p of each 16-lane group supplies the address of block row q, columns 4p..4p+3.
+__device__ __forceinline__ bf16x8 lds_trfrag(const bf16_t* T, int dt, int ta, int tb, int fr, int fq) {
+    const bf16_t* pa = T + (ta * 16 + 4 * fq + (fr >> 2)) * AB_PITCH + dt * 16 + 4 * (fr & 3);
+    const bf16_t* pb = T + (tb * 16 + 4 * fq + (fr >> 2)) * AB_PITCH + dt * 16 + 4 * (fr & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// snake deal of NT work items (sorted by decreasing weight) to 3 waves
+__device__ __forceinline__ int snake_owner(int rank) {
+    const int m = rank % (2 * AB_WAVES);
+    return m < AB_WAVES ? m : 2 * AB_WAVES - 1 - m;
+}
+
 template <int NT>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               bf16_t* __restrict__ dqkv, int nseq, int L, int heads,
                                                               int causal) {
     constexpr int LP = NT * 16;
-    constexpr int LDT = LP + 8;
     constexpr int NP = (NT + 1) / 2;  // pairs of 16-wide tiles = MFMA k-steps over a summed sequence index
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Ks = Qs + LP * AB_PITCH;
+    bf16_t* Vs = Ks + LP * AB_PITCH;
+    bf16_t* Os = Vs + LP * AB_PITCH;     // dO
+    float* lse_s = reinterpret_cast<float*>(Os + LP * AB_PITCH);
+    float* delta = lse_s + LP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int C = heads * HD;
     const long ld = 3L * C;
-    const int total = nseq * heads;
-    int item = blockIdx.x * AT_WAVES + wave;
-    const bool live = item < total;
-    if (!live) item = total - 1;
-    const int s = item / heads, h = item - s * heads;
+    const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
     const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
-    const bf16_t* kb = qb + C;
-    const bf16_t* vb = qb + 2 * C;
     const bf16_t* dob = dout + (long)s * L * C + h * HD;
     const float* lser = lse + ((long)s * heads + h) * L;
     bf16_t* dqb = dqkv + (long)s * L * ld + h * HD;
     bf16_t* dkb = dqb + C;
     bf16_t* dvb = dqb + 2 * C;
 
-    char* wbase = smem + (long)wave * (3 * HD * LDT * 2 + LP * 4);
-    bf16_t* Kt = reinterpret_cast<bf16_t*>(wbase);
-    bf16_t* Qt = Kt + HD * LDT;
-    bf16_t* dOt = Qt + HD * LDT;
-    float* delta = reinterpret_cast<float*>(dOt + HD * LDT);
-    stage_transposed(kb, ld, L, LP, Kt, LDT, lane);
-    stage_transposed(qb, ld, L, LP, Qt, LDT, lane);
-    stage_transposed(dob, C, L, LP, dOt, LDT, lane);
+    // ---- stage Q, K, V, dO (rows >= L zero-filled) and lse ----
+    for (int idx = threadIdx.x; idx < LP * 8 * 4; idx += AB_THREADS) {
+        const int which = idx / (LP * 8);
+        const int rem = idx - which * (LP * 8);
+        const int row = rem >> 3, ch = rem & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < L)
+            v = which < 3 ? *reinterpret_cast<const uint4*>(qb + (long)row * ld + which * C + ch * 8)
+                          : *reinterpret_cast<const uint4*>(dob + (long)row * C + ch * 8);
+        *reinterpret_cast<uint4*>(Qs + which * (LP * AB_PITCH) + row * AB_PITCH + ch * 8) = v;
+    }
+    for (int q = threadIdx.x; q < LP; q += AB_THREADS) lse_s[q] = q < L ? lser[q] : 0.f;
     __syncthreads();
     const float scale = 0.125f;
 
     // ---- pass 1: per query tile in the S^T orientation (query on the lane) -> delta, dQ ----
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int rank = 0; rank < NT; ++rank) {
+        if (snake_owner(rank) != wave) continue;
+        const int qt = NT - 1 - rank;              // heaviest (most visible keys) first
         const int q0 = qt * 16;
         const int query = q0 + fr;
         const int nkt = causal ? qt + 1 : NT;
-        const bf16x8 qf0 = gfrag(qb, ld, query, L, fq * 8), qf1 = gfrag(qb, ld, query, L, 32 + fq * 8);
-        const bf16x8 df0 = gfrag(dob, C, query, L, fq * 8), df1 = gfrag(dob, C, query, L, 32 + fq * 8);
-        const float lq = lser[query < L ? query : L - 1];
+        const bf16x8 qf0 = lds_rowfrag(Qs, query, 0, fq), qf1 = lds_rowfrag(Qs, query, 1, fq);
+        const bf16x8 df0 = lds_rowfrag(Os, query, 0, fq), df1 = lds_rowfrag(Os, query, 1, fq);
+        const float lq = lse_s[query];
         f32x4 pv[NT], ds[NT];
         float dl = 0.f;
 #pragma unroll
@@ -206,12 +248,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __re
             f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kt < nkt) {
                 const int krow = kt * 16 + fr;
-                const bf16x8 kf0 = gfrag(kb, ld, krow, L, fq * 8), kf1 = gfrag(kb, ld, krow, L, 32 + fq * 8);
-                const bf16x8 vf0 = gfrag(vb, ld, krow, L, fq * 8), vf1 = gfrag(vb, ld, krow, L, 32 + fq * 8);
-                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, sv, 0, 0, 0);
-                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, sv, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, df0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, df1, dp, 0, 0, 0);
+                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Ks, krow, 0, fq), qf0, sv, 0, 0, 0);
+                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Ks, krow, 1, fq), qf1, sv, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Vs, krow, 0, fq), df0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Vs, krow, 1, fq), df1, dp, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -240,13 +280,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __re
                 const f32x4 hi = (2 * ks + 1 < NT) ? ds[tb] : f32x4{0.f, 0.f, 0.f, 0.f};
                 const bf16x8 sf = pack_acc2(ds[ta], hi);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 kf = tfrag(Kt, LDT, dt * 16 + fr, ta, tb, fq);
-                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, acc[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Ks, dt, ta, tb, fr, fq), sf, acc[dt], 0, 0, 0);
             }
         }
-        if (live && query < L) {
+        if (query < L) {
             bf16_t* row = dqb + (long)query * ld;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -254,15 +292,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __re
                     make_uint2(pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3]));
         }
     }
-    __syncthreads();  // delta[] complete (same wave wrote it; barrier also orders the LDS accesses)
+    __syncthreads();  // delta[] complete
 
     // ---- pass 2: per key tile in the S orientation (key on the lane) -> dV, dK ----
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int rank = 0; rank < NT; ++rank) {
+        if (snake_owner(rank) != wave) continue;
+        const int kt = rank;                       // heaviest (seen by most queries) first
         const int k0 = kt * 16;
-        if (k0 >= L) break;
+        if (k0 >= L) continue;
         const int key = k0 + fr;
-        const bf16x8 kf0 = gfrag(kb, ld, key, L, fq * 8), kf1 = gfrag(kb, ld, key, L, 32 + fq * 8);
-        const bf16x8 vf0 = gfrag(vb, ld, key, L, fq * 8), vf1 = gfrag(vb, ld, key, L, 32 + fq * 8);
+        const bf16x8 kf0 = lds_rowfrag(Ks, key, 0, fq), kf1 = lds_rowfrag(Ks, key, 1, fq);
+        const bf16x8 vf0 = lds_rowfrag(Vs, key, 0, fq), vf1 = lds_rowfrag(Vs, key, 1, fq);
         f32x4 av[4], ak[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -282,22 +322,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __re
                 const bool tile_ok = qt < NT && qt * 16 < L && (!causal || qt >= kt);
                 if (tile_ok) {
                     const int qrow = qt * 16 + fr;
-                    const bf16x8 qf0 = gfrag(qb, ld, qrow, L, fq * 8), qf1 = gfrag(qb, ld, qrow, L, 32 + fq * 8);
-                    const bf16x8 df0 = gfrag(dob, C, qrow, L, fq * 8), df1 = gfrag(dob, C, qrow, L, 32 + fq * 8);
                     f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
                     // D[query][key]: A = Q rows (queries), B = K rows as columns (keys)
-                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0, kf0, sv, 0, 0, 0);
-                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, kf1, sv, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df0, vf0, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df1, vf1, dp, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Qs, qrow, 0, fq), kf0, sv, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Qs, qrow, 1, fq), kf1, sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Os, qrow, 0, fq), vf0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Os, qrow, 1, fq), vf1, dp, 0, 0, 0);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + fq * 4);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + qt * 16 + fq * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int query = qt * 16 + fq * 4 + r;
                         const bool ok = key < L && query < L && (!causal || key <= query);
-                        const int qc = query < L ? query : L - 1;
-                        const float p = ok ? __expf(sv[r] * scale - lser[qc]) : 0.f;
+                        const float p = ok ? __expf(sv[r] * scale - l4[r]) : 0.f;
                         pt[e][r] = p;
-                        dt2[e][r] = p * (dp[r] - delta[query]) * scale;
+                        dt2[e][r] = p * (dp[r] - d4[r]) * scale;
                     }
                 }
             }
@@ -306,13 +345,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const bf16_t* __re
             const bf16x8 sf = pack_acc2(dt2[0], dt2[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 of = tfrag(dOt, LDT, dt * 16 + fr, ta, tb, fq);   // dO^T[d][query]
-                const bf16x8 qf = tfrag(Qt, LDT, dt * 16 + fr, ta, tb, fq);    // Q^T[d][query]
-                av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, pf, av[dt], 0, 0, 0);  // dV^T[d,key]
-                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[dt], 0, 0, 0);  // dK^T[d,key]
+                av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Os, dt, ta, tb, fr, fq), pf, av[dt], 0, 0, 0);  // dV^T[d,key]
+                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Qs, dt, ta, tb, fr, fq), sf, ak[dt], 0, 0, 0);  // dK^T[d,key]
             }
         }
-        if (live && key < L) {
+        if (key < L) {
             bf16_t* vrow = dvb + (long)key * ld;
             bf16_t* krow = dkb + (long)key * ld;
 #pragma unroll
@@ -355,7 +392,7 @@ static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, 
 template <int NT>
 static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq, int L,
                       int heads, int causal, hipStream_t s) {
-    constexpr size_t lds = (size_t)AT_WAVES * (3 * HD * (NT * 16 + 8) * 2 + NT * 16 * 4);
+    constexpr size_t lds = (size_t)4 * NT * 16 * AB_PITCH * 2 + 2 * NT * 16 * 4;
     static bool attr = false;
     if (!attr) {
         int rc = check_hip(hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>,
@@ -363,8 +400,8 @@ static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* ls
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(cdiv((long)nseq * heads, AT_WAVES)), dim3(AT_THREADS), lds, s, qkv,
-                       dout, lse, dqkv, nseq, L, heads, causal);
+    hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, dout, lse, dqkv, nseq, L,
+                       heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_bwd");
     return NEAT_OK;
 }
