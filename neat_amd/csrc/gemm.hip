@@ -9,7 +9,8 @@
 // ridge), so the kernel is built around the ACTIVATION stream ("activation-stationary"):
 //
 //  * work unit = 128 rows x 256 columns; persistent grid of TWO 512-thread workgroups per CU (16 waves,
-//    4 per SIMD, <= 128 VGPRs each), units dealt round-robin.  Two independent workgroups per CU drift out
+//    4 per SIMD, <= 128 VGPRs each); units are dealt so that all column blocks of a sub-panel run on one
+//    XCD (one L2): measured with FETCH_SIZE, the plain round-robin deal fetched every panel N/256 times.  Two independent workgroups per CU drift out
 //    of phase, so one's epilogue (a per-CU store stream of ~10 B/clk) overlaps the other's MFMAs;
 //  * the unit's 128-row sub-panel streams through LDS in [128 x 128-k] pieces, double buffered
 //    (2 x 32 KiB), filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).  The LDS image is
@@ -87,11 +88,7 @@ __device__ __forceinline__ void piece_mma(f32x4 (&acc)[NI][8], const uint4* __re
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-#ifndef NEAT_ABL_NOMFMA
                     acc[i][tg + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[t], acc[i][tg + t], 0, 0, 0);
-#else
-                    asm volatile("" :: "v"(wf[i]), "v"(af[t]));
-#endif
         }
     }
 }
@@ -115,20 +112,34 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
     const int fr = lane & 15, fq = lane >> 4;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;  // LDS byte address
 
+    // Unit -> workgroup deal, XCD-aware.  Workgroups are placed on the 8 XCDs round-robin by blockIdx (used for
+    // speed only, never for correctness), and each XCD has its own L2.  All column blocks of one 128-row
+    // sub-panel are therefore dealt to workgroups of ONE XCD (sub-panel s belongs to XCD s % 8): the panel is
+    // fetched from the fabric once instead of once per column block.
     const int nsub = (M + 127) >> 7;
     const int ncb = (N + CB - 1) / CB;
-    const int nunits = nsub * ncb;
     const int G = gridDim.x;
-    const int myunits = (nunits - (int)blockIdx.x + G - 1) / G;   // units blockIdx.x, +G, +2G, ...
+    const int X = (G & 7) == 0 ? 8 : 1;              // XCDs the deal is spread over
+    const int xcd = blockIdx.x % X, wg = blockIdx.x / X, WX = G / X;
+    const int nsx = (nsub - xcd + X - 1) / X;        // sub-panels xcd, xcd+X, ... owned by this XCD
+    const int myunits = (nsx * ncb - wg + WX - 1) / WX;           // local units wg, wg+WX, ...
     if (myunits <= 0) return;                                     // uniform
+    auto unit_of = [&](int t, int& sub, int& cb) {                // t-th unit of this workgroup
+        const int v = wg + t * WX;
+        const int i = v / ncb;
+        cb = v - i * ncb;
+        sub = xcd + X * i;
+    };
     const int nkh = K / BKH;                         // pieces along K
     const int ksK = K >> 5;                          // k-steps in the whole K (packed-W stride)
     const int J = myunits * nkh;                     // pieces this workgroup consumes
 
     auto issue_piece = [&](int j) {
-        const int u = blockIdx.x + (j / nkh) * G;
-        const int kh = j % nkh;
-        const int row0 = (u / ncb) << 7;
+        const int t = j / nkh;
+        const int kh = j - t * nkh;
+        int sub_, cb_;
+        unit_of(t, sub_, cb_);
+        const int row0 = sub_ << 7;
         const uint32_t buf = lds_base + (j & 1) * P_BUF_BYTES;
         const bf16_t* src = A + kh * BKH;
         for (int q = (wave & 3); q < ninstr; q += 4) {
@@ -145,9 +156,10 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
 
     f32x4 acc[NI][8];
     for (int j = 0; j < J; ++j) {
-        const int u = blockIdx.x + (j / nkh) * G;
-        const int kh = j % nkh;
-        const int sub = u / ncb, cb = u - sub * ncb;
+        const int tu = j / nkh;
+        const int kh = j - tu * nkh;
+        int sub, cb;
+        unit_of(tu, sub, cb);
 
         // piece j is in LDS (its fillers waited vmcnt(0) before arriving here) and nobody reads buffer
         // (j+1)&1 any more.  Raw barrier: no vmcnt(0), so epilogue stores keep draining behind it.
@@ -172,17 +184,7 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
             // the fills this wave issued for piece j+1 have had the whole k-loop to land; retire them BEFORE
             // the epilogue stores so that the next barrier needs no vmcnt wait
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef NEAT_ABL_NOSTORE
             if (kh == nkh - 1) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(acc[i][t]));
-            }
-            if (kh == nkh - 1 && M < 0) {
-#else
-            if (kh == nkh - 1) {
-#endif
                 // Epilogue.  The accumulator holds 4 consecutive columns per lane but 16 different ROWS per
                 // wave-instruction (32-B requests).  Each 16 x (NI*16) tile is therefore transposed through a
                 // wave-private 4-KiB LDS slab (XOR-swizzled 16-B chunks, conflict-free both ways) so that
@@ -304,15 +306,15 @@ static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias,
                        const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
     const int cus = num_cus();
     const long units = (long)cdiv(M, 128) * cdiv(N, P_WAVES * P_NI * 16);
-    const int grid = (int)(units < 2 * cus ? units : 2 * cus);   // persistent: two workgroups per CU
+    // persistent: two workgroups per CU; a multiple of 8 so that the XCD-aware deal applies
+    const long want = (units + 7) / 8 * 8;
+    const int grid = (int)(want < 2 * cus ? want : 2 * cus);
     return launch_gemm_c<EPI, P_BKH, P_NI, 2>(A, Wp, bias, res, aux, out0, out1, M, N, K, grid, s);
 }
 
 }  // namespace neat
 
 using namespace neat;
-
-extern "C" long neat_packed_weight_elems(int N, int K) { return (long)N * K; }
 
 extern "C" int neat_pack_weight_bf16(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream) {
     NEAT_REQUIRE(src && dst, NEAT_ERR_ARG, "neat_pack_weight_bf16: null pointer");

@@ -174,19 +174,23 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     for (int c = threadIdx.x; c < 2 * cols; c += LN_THREADS) dst[c] = red[c];
 }
 
-// 64 columns x 4 row-slices per block: coalesced 256-B reads, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int cols,
-                                                              float* dgamma, float* dbeta, int accumulate) {
-    __shared__ float red[4][64];
+// 64 columns x 16 row-slices per block: coalesced 256-B reads, fixed summation order (deterministic)
+constexpr int LNF_SLICES = 16;
+__global__ __launch_bounds__(64 * LNF_SLICES) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                         int cols, float* dgamma, float* dbeta,
+                                                                         int accumulate) {
+    __shared__ float red[LNF_SLICES][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < 2 * cols)
-        for (int b = slice; b < nblk; b += 4) s += partial[(long)b * 2 * cols + c];
+        for (int b = slice; b < nblk; b += LNF_SLICES) s += partial[(long)b * 2 * cols + c];
     red[slice][lane] = s;
     __syncthreads();
     if (slice == 0 && c < 2 * cols) {
-        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNF_SLICES; ++k) s += red[k][lane];
         float* dst = (c < cols) ? dgamma + c : dbeta + (c - cols);
         *dst = accumulate ? (*dst + s) : s;
     }
@@ -221,10 +225,10 @@ extern "C" int neat_ln_fwd(const float* x, const float* gamma, const float* beta
 }
 
 extern "C" int neat_ln_bwd_blocks(int rows) {
-    // every block leaves one partial row pair behind, so keep the grid at ~2 blocks per CU: the streaming
-    // part stays HBM-bound (8 waves/CU x 16 B loads) and the finalize pass reads only 512 partial rows
-    int g = cdiv(rows, LN_WAVES * 16);
-    return g < 1 ? 1 : (g > 512 ? 512 : g);
+    // every block leaves one partial row pair behind; 4 blocks (16 waves) per CU keep the streaming part
+    // HBM-bound, and the finalize pass reads at most 1024 partial rows
+    int g = cdiv(rows, LN_WAVES * 8);
+    return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
 extern "C" int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
@@ -251,7 +255,7 @@ extern "C" int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, fl
                                     int accumulate, void* stream) {
     NEAT_REQUIRE(partial && dgamma && dbeta, NEAT_ERR_ARG, "neat_ln_bwd_finalize: null pointer");
     NEAT_REQUIRE(nblk > 0 && cols > 0, NEAT_ERR_SHAPE, "neat_ln_bwd_finalize: bad shape");
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(2 * cols, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(2 * cols, 64)), dim3(64 * LNF_SLICES), 0, (hipStream_t)stream,
                        partial, nblk, cols, dgamma, dbeta, accumulate);
     NEAT_LAUNCH_CHECK("neat_ln_bwd_finalize");
     return NEAT_OK;

@@ -1,0 +1,170 @@
+"""Data-parallel host logic of train_TTA.tta_step on CPU: world_size 2, gloo.
+
+The kernels need an MI355X, so here the three kernel-backed calls of tta_step (text tower forward/backward,
+coarse alignment, row-sharded loss) are replaced -- in the TEST only -- by CPU stand-ins built from the oracle.
+Everything else is the product code: row sharding (uneven shards), padded all-gather of text / coarse
+features, all-reduce of the LayerNorm gradients and of the per-rank loss sums, optimizer step on every rank.
+Pass criterion: after two steps every rank holds the LN parameters, losses and score rows that the
+single-process oracle produces on the whole batch (reference train_TTA.py:133-147; main_TTA.py:221-226 for
+the reference's own DistributedSampler sharding).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+T1, T2, LR, WD = 0.03, 0.07, 2e-4, 1e-3
+MODEL, B, NIMG, STEPS = "neat-tiny", 7, 12, 2     # 7 rows -> shards of 4 and 3
+
+
+def _sharded_loss_cpu(t, p, v, t_all, c_all, T1, T2, row0):
+    """CPU stand-in for ops.tta_loss_fwd_bwd with the same contract as neat_tta_loss_fwd_bwd
+    (include/neat_hip.h): local rows [row0, row0+Bl) of a global batch of B rows; losses[0] is the global
+    entropy term, losses[1:] are this rank's contributions (sum over local rows / B)."""
+    B, Bl = t_all.shape[0], t.shape[0]
+    sl = slice(row0, row0 + Bl)
+    Z = (c_all @ t_all.t()) / T1
+    logp = torch.log_softmax(Z, dim=1)
+    P = logp.exp()
+    H = -(P * logp).sum(1)
+    l_ent = H.mean()
+    dZ = -P * (logp + H.unsqueeze(1)) / B
+    dt = (dZ[:, sl].t() @ c_all) / T1
+    U = v @ c_all.t()
+    ar = torch.arange(Bl)
+    diag = U[ar, ar + row0].unsqueeze(1)
+    raw = diag - U
+    cost = raw.clamp(min=0)
+    cost[ar, ar + row0] = 0.0
+    m, j = cost.max(dim=1)
+    l_sr = m.sum() / (B * T2)
+    act = (raw[ar, j] >= 0) & (j != ar + row0)
+    gsr = act.to(t.dtype) / (B * T2)
+    dU = torch.zeros_like(U)
+    dU[ar, j] -= gsr
+    dU[ar, ar + row0] += gsr
+    dv = dU @ c_all
+    e_tv, e_tp = t - v + 1e-6, t - p + 1e-6
+    d_tv, d_tp = e_tv.norm(dim=1), e_tp.norm(dim=1)
+    l_tri = ((2.0 - d_tv).sum() + 5.0 * d_tp.sum()) / B
+    g_tv, g_tp = e_tv / d_tv.unsqueeze(1) / B, e_tp / d_tp.unsqueeze(1) / B
+    return torch.stack([l_ent, l_sr, l_tri]), dt - g_tv + 5.0 * g_tp, -5.0 * g_tp, dv + g_tv
+
+
+class _OracleTower:
+    """Text tower with the engine.TextTower interface, computed by the CPU oracle on the model's live
+    parameters."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def _sd(self):
+        return {k: v.detach() for k, v in self.model.state_dict().items()}
+
+    def forward(self, tokens, normalize, save):
+        from oracle import neat_oracle as O
+        feat, cache = O.encode_text_fwd(self._sd(), tokens, normalize, save=save)
+        return feat, cache
+
+    def backward(self, ctx, dfeat, grads, accumulate):
+        from oracle import neat_oracle as O
+        n_all = ctx["shape"][0]
+        d = torch.zeros(n_all, dfeat.shape[1])
+        d[: dfeat.shape[0]] = dfeat             # sequences beyond the first n_grad carry no gradient
+        named = O.encode_text_bwd(self._sd(), ctx, d, {})
+        for i, g in enumerate(grads):
+            for key, nm in (("ln1_w", "ln_1.weight"), ("ln1_b", "ln_1.bias"), ("ln2_w", "ln_2.weight"),
+                            ("ln2_b", "ln_2.bias")):
+                src = named[f"transformer.resblocks.{i}.{nm}"]
+                g[key].copy_(g[key] + src if accumulate else src)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neat_amd import open_clip as oc, ops, synth
+        from neat_amd import train_TTA as T
+        from oracle import neat_oracle as O
+
+        model = oc.create_model(MODEL, device="cpu")
+        model.load_state_dict(synth.synth_state_dict(MODEL, 0))
+        oc.freeze_parameters(model, False)
+        params, _ = oc.collect_params(model, False)
+        opt = torch.optim.AdamW(params, lr=LR, weight_decay=WD)
+        tower = _OracleTower(model)
+        model._text_tower = lambda: tower
+        # test-only stand-ins for the three kernel-backed calls
+        ops.coarse_align = lambda t, p, n, G: O.coarse_align_t2i(t, p, n, G)
+        ops.tta_loss_fwd_bwd = _sharded_loss_cpu
+
+        cfg = synth.get_cfg(MODEL)["text_cfg"]
+        toks = synth.synth_caption_sets(B, cfg["context_length"], cfg["vocab_size"], 77)
+        gen = torch.Generator().manual_seed(5)
+        G = torch.nn.functional.normalize(torch.randn(NIMG, 512, generator=gen), dim=-1)
+        lo, hi = T._shard(B, world, rank)
+        local = [x[lo:hi].contiguous() for x in toks]
+        for _ in range(STEPS):
+            losses, idx, S = T.tta_step(model, opt, local, G, T1, T2, world, rank)
+        S_all = T._all_gather_rows(S, B, world)
+        torch.save(dict(losses=losses, S=S_all, idx=idx, lo=lo,
+                        params={k: v.detach().clone() for k, v in model.state_dict().items() if ".ln_" in k}),
+                   os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_covers_rows_in_order():
+    from neat_amd.train_TTA import _shard
+    for n in (0, 1, 7, 256, 25014):
+        for w in (1, 2, 3, 8):
+            spans = [_shard(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_tta_step_world2_matches_single_process_oracle(tmp_path):
+    from neat_amd import synth
+    from oracle import neat_oracle as O
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+
+    sd = synth.synth_state_dict(MODEL, 0)
+    cfg = synth.get_cfg(MODEL)["text_cfg"]
+    toks = synth.synth_caption_sets(B, cfg["context_length"], cfg["vocab_size"], 77)
+    gen = torch.Generator().manual_seed(5)
+    G = torch.nn.functional.normalize(torch.randn(NIMG, 512, generator=gen), dim=-1)
+    st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
+    for _ in range(STEPS):
+        losses, idx, S, _, _ = O.tta_step(sd, st, toks, G, LR, WD, T1, T2)
+
+    for r in (r0, r1):
+        torch.testing.assert_close(r["losses"], losses, rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(r["S"], S, rtol=1e-5, atol=1e-6)
+        for k, v in r["params"].items():
+            if k.startswith("transformer."):
+                torch.testing.assert_close(v, sd[k], rtol=1e-5, atol=1e-7, msg=lambda m, k=k: f"{k}: {m}")
+    # ranks agree bit for bit (same reduced gradients, same optimizer arithmetic)
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    assert torch.equal(torch.cat([r0["idx"], r1["idx"]]), idx)
+    assert (r0["lo"], r1["lo"]) == (0, 4)
