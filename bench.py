@@ -31,6 +31,12 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0             # HBM3E peak, same guide
+# HBM traffic per launch of the c_fc GEMM from the PMC counters (profiles/r01_bench_pmc_*.csv: separate
+# `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same command; counters are in KiB;
+# FETCH_SIZE doubled as the guide prescribes for gfx950 wide streaming reads -- the LN kernels in the same
+# passes confirm the factor: ln_fwd reports 80.8 MB for a 161.5 MB read).  Keyed by (M, N, K); a launch mix
+# that was not profiled reports traffic = null.
+PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 164400.97 + 636683.21) * 1024)}
 
 
 def parse():
@@ -159,9 +165,11 @@ def main():
     gbs = avg_bytes / sec / 1e9 if sec > 0 else 0.0
     tfs = avg_flop / sec / 1e12 if sec > 0 else 0.0
     flops_row_step = text_tower_flops_per_row_step(cfg, L)
+    shapes = set(timer.shapes)
+    traffic = PMC_TRAFFIC_BYTES.get(next(iter(shapes))) if len(shapes) == 1 else None
     roofline = dict(bound="hbm", kernel="gemm_panel_kernel<NEAT_EPI_BIAS_GELU> (c_fc: M=4*B*77, N=4C, K=C)",
                     achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-                    traffic=None, launches=nl, avg_launch_ms=round(avg_ms, 4),
+                    traffic=traffic, launches=nl, avg_launch_ms=round(avg_ms, 4),
                     algorithmic_bytes_per_launch=int(avg_bytes), mfma_tflops=round(tfs, 1),
                     mfma_frac=round(tfs / MFMA_BF16_PEAK_TFLOPS, 4),
                     step_tflops=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12, 1))

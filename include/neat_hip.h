@@ -125,8 +125,10 @@ int neat_coarse_align(const float* q, const float* pos, const float* neg, const 
 
 /* ---- TTA loss forward + gradient, train_TTA.py:138-143 with :45-48, :53-65, :77-91 ---- */
 /* text,pos,inv f32 [Bl,D] are this rank's rows [row0,row0+Bl) of the global batch; text_all/coarse_all
- * f32 [B,D] are all B rows (== text/coarse when single-GPU).  losses f32 [3] = entropy, sr, triplet of
- * the GLOBAL batch (every rank computes the same value); dtext,dpos,dinv f32 [Bl,D].
+ * f32 [B,D] are all B rows (== text/coarse when single-GPU).  losses f32 [3]: [0] = entropy term of the
+ * GLOBAL batch (identical on every rank); [1], [2] = this rank's share of the sr / triplet terms (sum over
+ * its rows, already divided by B) -- their sum over ranks is the global value, and with Bl == B they ARE the
+ * global values.  dtext,dpos,dinv f32 [Bl,D] = d(total loss)/d(local rows).
  * ws f32 workspace of neat_loss_ws_floats(B,Bl) floats. */
 long neat_loss_ws_floats(int B, int Bl);
 int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const float* inv, const float* text_all,
