@@ -23,8 +23,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// one v_cvt_pk_bf16_f32: lo -> bits 0..15, hi -> bits 16..31
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -41,10 +45,15 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// sigmoid(1.702 x) in three instructions (v_mul, v_exp, v_add, v_rcp: hardware exp2 / rcp, ~1 ulp each --
+// far inside the bf16 rounding that follows every use).  exp2 -> +inf gives rcp -> 0, the right limit.
+__device__ __forceinline__ float sigmoid1702(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.44269504088896341f)));
+}
 // QuickGELU, reference open_clip/transformer.py:33-36
-__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoid1702(x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
-    float s = sigmoidf_(1.702f * x);
+    float s = sigmoid1702(x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 

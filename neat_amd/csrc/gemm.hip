@@ -40,9 +40,11 @@ constexpr int P_THREADS = 512;
 constexpr int P_WAVES = 8;                // per workgroup; two workgroups per CU -> 4 waves per SIMD
 constexpr int P_NI = 2;                   // 16-column tiles per wave: a unit is 128 rows x 256 columns
 constexpr int P_BKH = 128;                // k extent of one LDS piece
-// LDS: two [128 x BKH] bf16 pieces + one epilogue slab (16 rows x NI*16 fp32) per wave
+// LDS: two [128 x BKH] bf16 pieces = 64 KiB, so that TWO workgroups fit a CU's 160 KiB (with separate epilogue
+// slabs a workgroup needed exactly 80 KiB and only one was ever resident); the per-wave epilogue slabs
+// (16 rows x NI*16 fp32) alias the piece that was consumed last
 constexpr int lds_piece_bytes(int bkh) { return 128 * bkh * 2; }
-constexpr int lds_total_bytes(int bkh, int ni) { return 2 * lds_piece_bytes(bkh) + P_WAVES * ni * 1024; }
+constexpr int lds_total_bytes(int bkh, int ni) { return 2 * lds_piece_bytes(bkh); }   // epilogue slabs alias a piece
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 B -> lds_dst .. lds_dst+1023 (lane-linear)
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
@@ -106,7 +108,6 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
     constexpr int ninstr = 128 * cpr / 64;           // wave-instructions per piece
     constexpr int CB = P_WAVES * NI * 16;            // columns per unit
     constexpr int P_BUF_BYTES = lds_piece_bytes(BKH);
-    constexpr int P_LDS_BYTES = 2 * P_BUF_BYTES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -181,68 +182,117 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
 #pragma unroll
             for (int i = 0; i < NI; ++i) woff[i] = (long)(i < nvalid ? i : nvalid - 1) * ksK * 64;
             piece_mma<NI, BKH>(acc, wp, woff, buf + fr * (cpr * 16), fr, fq);
-            // the fills this wave issued for piece j+1 have had the whole k-loop to land; retire them BEFORE
-            // the epilogue stores so that the next barrier needs no vmcnt wait
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (kh == nkh - 1) {
+        }
+        // the fills this wave issued for piece j+1 have had the whole k-loop to land; retire them BEFORE the
+        // epilogue stores so that the next barrier needs no vmcnt wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kh == nkh - 1) {                                        // uniform over the workgroup
+            // every wave is done reading piece j: its buffer now holds the epilogue slabs, until the fill of
+            // piece j+2 is issued behind the NEXT barrier (which each wave reaches after its epilogue)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (nvalid > 0) {
                 // Epilogue.  The accumulator holds 4 consecutive columns per lane but 16 different ROWS per
                 // wave-instruction (32-B requests).  Each 16 x (NI*16) tile is therefore transposed through a
-                // wave-private 4-KiB LDS slab (XOR-swizzled 16-B chunks, conflict-free both ways) so that
-                // consecutive lanes cover one row: every global access below is a whole 128/256-B line.
-                char* stg = lds + P_LDS_BYTES + wave * (NI * 1024);
+                // wave-private LDS slab (XOR-swizzled 16-B chunks, conflict-free both ways) so that consecutive
+                // lanes cover one row and every lane moves 16 B per global access.
+                char* stg = lds + (j & 1) * P_BUF_BYTES + wave * (NI * 1024);
                 constexpr int CPW = NI * 4;                             // 16-B fp32 chunks per row of the slab
-                constexpr int RPI = 64 / CPW;                           // rows per read instruction
                 const int ncols = nvalid < NI ? nvalid * 16 : NI * 16;  // valid columns of this wave's slab
-                const int cl = lane % CPW, rq = lane / CPW;
-                const int n = nt0 * 16 + cl * 4;
-                const bool col_ok = cl * 4 < ncols;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU) {
-                    if (col_ok) bv = *reinterpret_cast<const float4*>(bias + n);
-                }
                 const int rowm0 = sub << 7;
+                if constexpr (EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32) {
+                    // fp32 outputs: a lane owns 4 columns (16 B), 8 lanes cover a 128-B row segment
+                    constexpr int RPI = 64 / CPW;                       // rows per read instruction
+                    const int cl = lane % CPW, rq = lane / CPW;
+                    const int n = nt0 * 16 + cl * 4;
+                    const bool col_ok = cl * 4 < ncols;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                        if (col_ok) bv = *reinterpret_cast<const float4*>(bias + n);
+                    }
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < 8; ++t) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
-                        *reinterpret_cast<f32x4*>(stg + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
+                        for (int i = 0; i < NI; ++i)
+                            *reinterpret_cast<f32x4*>(stg + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
 #pragma unroll
-                    for (int r = 0; r < 16 / RPI; ++r) {
-                        const int row = r * RPI + rq;
-                        const float4 a4 = *reinterpret_cast<const float4*>(stg + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
-                        const int m = rowm0 + t * 16 + row;
+                        for (int r = 0; r < 16 / RPI; ++r) {
+                            const int row = r * RPI + rq;
+                            const float4 a4 = *reinterpret_cast<const float4*>(stg + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
+                            const int m = rowm0 + t * 16 + row;
+                            if (m >= M || !col_ok) continue;
+                            const long o = (long)m * N + n;
+                            float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+                            if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                                const float4 rr = *reinterpret_cast<const float4*>(res + o);
+                                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
+                            } else {
+                                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0, v1, v2, v3);
+                            }
+                        }
+                    }
+                } else {
+                    // bf16 outputs: a lane owns 8 columns (16 B of bf16), 4 lanes cover the wave's 32 columns,
+                    // one wave-instruction covers the whole 16-row tile.  Slab swizzle sw(r) is conflict-free for
+                    // the ds_write_b128 lane groups (8 contiguous lanes) and the ds_read_b128 ones.
+                    static_assert(NI == 2, "bf16 epilogue assumes a 32-column slab");
+                    auto sw = [](int r) { return (r & 3) ^ ((r & 4) ? 5 : 0); };
+                    const int er = lane >> 2, eq = lane & 3;
+                    const int n = nt0 * 16 + eq * 8;
+                    const bool col_ok = eq * 8 < ncols;
+                    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_GELU) {
+                        if (col_ok) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
+                            const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+                            bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                        }
+                    }
+                    const char* rd0 = stg + er * 128 + (((2 * eq) ^ sw(er)) << 4);
+                    const char* rd1 = stg + er * 128 + (((2 * eq + 1) ^ sw(er)) << 4);
+                    char* wr = stg + fr * 128;
+                    const int wsw = sw(fr);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+                            *reinterpret_cast<f32x4*>(wr + (((i * 4 + fq) ^ wsw) << 4)) = acc[i][t];
+                        const float4 a0 = *reinterpret_cast<const float4*>(rd0);
+                        const float4 a1 = *reinterpret_cast<const float4*>(rd1);
+                        const int m = rowm0 + t * 16 + er;
                         if (m >= M || !col_ok) continue;
                         const long o = (long)m * N + n;
-                        float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+                        float v[8] = {a0.x + bv[0], a0.y + bv[1], a0.z + bv[2], a0.w + bv[3],
+                                      a1.x + bv[4], a1.y + bv[5], a1.z + bv[6], a1.w + bv[7]};
                         if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
-                            *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-                        } else if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                            const float4 rr = *reinterpret_cast<const float4*>(res + o);
-                            *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
+                            *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
+                                pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
                         } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
                             // the saved pre-activation is the bf16-rounded value; GELU is applied to the same
                             // rounded value so that forward and backward see one h
-                            const uint2 hp = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-                            if (out0) *reinterpret_cast<uint2*>((bf16_t*)out0 + o) = hp;
-                            const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
-                            const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
-                            *reinterpret_cast<uint2*>((bf16_t*)out1 + o) = make_uint2(
-                                pack2bf(quick_gelu(h0), quick_gelu(h1)), pack2bf(quick_gelu(h2), quick_gelu(h3)));
-                        } else if constexpr (EPI == NEAT_EPI_GELU_BWD) {
-                            const uint2 hp = *reinterpret_cast<const uint2*>(aux + o);
-                            const float h0 = __uint_as_float(hp.x << 16), h1 = __uint_as_float(hp.x & 0xffff0000u);
-                            const float h2 = __uint_as_float(hp.y << 16), h3 = __uint_as_float(hp.y & 0xffff0000u);
-                            *reinterpret_cast<uint2*>((bf16_t*)out0 + o) =
-                                make_uint2(pack2bf(v0 * quick_gelu_grad(h0), v1 * quick_gelu_grad(h1)),
-                                           pack2bf(v2 * quick_gelu_grad(h2), v3 * quick_gelu_grad(h3)));
-                        } else {  // NEAT_EPI_F32
-                            *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0, v1, v2, v3);
+                            uint32_t hp[4], up[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+                                const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
+                            }
+                            if (out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                            *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
+                        } else {  // NEAT_EPI_GELU_BWD
+                            const uint4 hq = *reinterpret_cast<const uint4*>(aux + o);
+                            const uint32_t hp[4] = {hq.x, hq.y, hq.z, hq.w};
+                            uint32_t dp[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
+                            }
+                            *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
                         }
                     }
                 }
             }
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
