@@ -13,7 +13,7 @@
 //    XCD (one L2): measured with FETCH_SIZE, the plain round-robin deal fetched every panel N/256 times.  Two independent workgroups per CU drift out
 //    of phase, so one's epilogue (a per-CU store stream of ~10 B/clk) overlaps the other's MFMAs;
 //  * the unit's 128-row sub-panel streams through LDS in [128 x 128-k] pieces, double buffered
-//    (2 x 32 KiB), filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).  The LDS image is
+//    (2 x 32 KiB = all the LDS a workgroup owns, so two of them fit a CU), filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).  The LDS image is
 //    lane-linear; the bank-conflict XOR swizzle (16-B chunk ^= row & 15) is applied to the per-lane SOURCE
 //    address and to the ds_read_b128 address.  ONE raw barrier per piece, with no vmcnt drain, so epilogue
 //    stores keep flowing behind it;
@@ -26,8 +26,9 @@
 //  * the LDS-DMA fills are issued from inline asm by a rotating half of the waves (one per SIMD) so that
 //    the in-order vmcnt queue of the OTHER wave on each SIMD only ever holds L2-latency weight loads:
 //    while a filling wave waits out its HBM-latency fills, its SIMD partner keeps the MFMA pipe busy;
-//  * epilogue: each 16 x 32 accumulator tile is transposed through a wave-private LDS slab so that every
-//    global access (bias, residual, saved activation, output) is a whole 128-B line.
+//  * epilogue: each 16 x 32 accumulator tile is transposed through a wave-private LDS slab (aliasing the piece
+//    consumed last) so that every lane moves 16 B per global access (bias, residual, saved activation,
+//    output) and a row's bytes are contiguous.
 //
 // Rows >= M are clamped on load and masked on store; N needs % 16, K needs % 128.
 #include <stdlib.h>
