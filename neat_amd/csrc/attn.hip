@@ -2,8 +2,10 @@
 // Replaces the SDPA core of nn.MultiheadAttention (reference open_clip/transformer.py:202,227-229,
 // causal mask :655-661) and its autograd backward.  head_dim is 64 for every CLIP ViT config.
 //
-// One 64-lane wavefront owns one (sequence, head); the whole score matrix of a head lives in MFMA
-// accumulators (L <= 272), so there is no online-softmax rescaling and no HBM round trip for S/P.
+// The whole score matrix of a head lives in MFMA accumulators (L <= 272), so there is no online-softmax
+// rescaling and no HBM round trip for S/P.  Short sequences (L <= 80: text, ViT-B/32 vision) use three
+// wavefronts per (sequence, head) over LDS-staged row-major tiles, forward and backward; longer vision
+// sequences use one wavefront per (sequence, head) (forward only).
 //
 // Orientation trick (guide §3 "accumulator tile as the next MFMA's operand"): scores are computed
 // TRANSPOSED, S^T = K.Q^T, so the accumulator of v_mfma_f32_16x16x32_bf16 holds for one query
@@ -188,6 +190,129 @@ __device__ __forceinline__ int snake_owner(int rank) {
     return m < AB_WAVES ? m : 2 * AB_WAVES - 1 - m;
 }
 
+// Stage NW row-major [LP x 64] bf16 tiles (Q|K|V at column offsets 0, C, 2C of qkv; tile 3 = dO) into LDS with
+// pitch AB_PITCH.  U independent 16-B loads per thread are issued before the first LDS store, so that a
+// workgroup has its whole tile set in flight at once (rows >= L are zero-filled).
+template <int NW, int U, int LP>
+__device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long ld, int C, const bf16_t* dob, int L) {
+    constexpr int total = LP * 8 * NW;
+    for (int base = 0; base < total; base += U * AB_THREADS) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * AB_THREADS + threadIdx.x;
+            const int which = idx / (LP * 8);
+            const int rem = idx - which * (LP * 8);
+            const int row = rem >> 3, ch = rem & 7;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (idx < total && row < L)
+                v[u] = which < 3 ? *reinterpret_cast<const uint4*>(qb + (long)row * ld + which * C + ch * 8)
+                                 : *reinterpret_cast<const uint4*>(dob + (long)row * C + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * AB_THREADS + threadIdx.x;
+            const int which = idx / (LP * 8);
+            const int rem = idx - which * (LP * 8);
+            const int row = rem >> 3, ch = rem & 7;
+            if (idx < total) *reinterpret_cast<uint4*>(dst + which * (LP * AB_PITCH) + row * AB_PITCH + ch * 8) = v[u];
+        }
+    }
+}
+
+// ---- forward for short sequences (NT <= 5: text L = 77, ViT-B/32 vision L = 50): same 3-wave, LDS-staged
+// structure as the backward.  Q, K, V of one (sequence, head) are staged once, row-major, with coalesced 16-B
+// loads; V^T fragments come from ds_read_b64_tr_b16; the O tile goes back through LDS (the wave's own Q rows)
+// so that the output leaves as whole 128-B rows, 16 B per lane.
+template <int NT>
+__global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv,
+                                                               bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                               int nseq, int L, int heads, int causal) {
+    constexpr int LP = NT * 16;
+    constexpr int NP = (NT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Ks = Qs + LP * AB_PITCH;
+    bf16_t* Vs = Ks + LP * AB_PITCH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int C = heads * HD;
+    const long ld = 3L * C;
+    const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
+    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
+
+    stage_tiles<3, (LP * 8 * 3 + AB_THREADS - 1) / AB_THREADS, LP>(Qs, qb, ld, C, nullptr, L);
+    __syncthreads();
+    const float scale = 0.125f;  // 1/sqrt(64)
+
+    for (int rank = 0; rank < NT; ++rank) {
+        if (snake_owner(rank) != wave) continue;
+        const int qt = causal ? NT - 1 - rank : rank;   // causal: heaviest tile first
+        const int q0 = qt * 16;
+        if (q0 >= L) continue;
+        const int query = q0 + fr;
+        const int nkt = causal ? qt + 1 : NT;
+        const bf16x8 qf0 = lds_rowfrag(Qs, query, 0, fq), qf1 = lds_rowfrag(Qs, query, 1, fq);
+        f32x4 st[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                const int krow = kt * 16 + fr;
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Ks, krow, 0, fq), qf0, st[kt], 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_rowfrag(Ks, krow, 1, fq), qf1, st[kt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fq * 4 + r;
+                const bool ok = kt < nkt && key < L && (!causal || key <= query);
+                st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        }
+        mx = xor_max_16_32(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[kt][r] = __expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
+                sum += st[kt][r];
+            }
+        sum = xor_sum_16_32(sum);
+        if (lse && fq == 0 && query < L) lse[((long)s * heads + h) * L + query] = mx + __logf(sum);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NP; ++ks) {
+            if (2 * ks < nkt) {
+                const int ta = 2 * ks, tb = (2 * ks + 1 < NT) ? 2 * ks + 1 : 2 * ks;
+                const f32x4 hi = (2 * ks + 1 < NT) ? st[tb] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x8 pf = pack_acc2(st[ta], hi);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Vs, dt, ta, tb, fr, fq), pf, o[dt], 0, 0, 0);
+            }
+        }
+        // O tile -> the wave's own (already consumed) Q rows -> global, 16 B per lane, 8 lanes per 128-B row
+        const float inv = 1.0f / sum;
+        bf16_t* qrow = Qs + query * AB_PITCH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(qrow + dt * 16 + fq * 4) =
+                make_uint2(pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = half * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(Qs + (q0 + r) * AB_PITCH + ch * 8);
+            if (q0 + r < L) *reinterpret_cast<uint4*>(out + ((long)s * L + q0 + r) * C + h * HD + ch * 8) = v;
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
@@ -205,6 +330,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
     float* delta = lse_s + LP;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // per-wave [16 x 64] bf16 tile through which result tiles leave as whole 128-B rows (16 B per lane)
+    bf16_t* xs = reinterpret_cast<bf16_t*>(delta + LP) + wave * (16 * AB_PITCH);
     const int fr = lane & 15, fq = lane >> 4;
     const int C = heads * HD;
     const long ld = 3L * C;
@@ -216,17 +343,22 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
     bf16_t* dkb = dqb + C;
     bf16_t* dvb = dqb + 2 * C;
 
+    // acc[dt] holds T^T[d = dt*16 + 4fq + r][row = fr] of a 16-row result tile starting at sequence row r0
+    auto store_tile = [&](const f32x4 (&a)[4], bf16_t* gbase, int r0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(xs + fr * AB_PITCH + dt * 16 + fq * 4) =
+                make_uint2(pack2bf(a[dt][0], a[dt][1]), pack2bf(a[dt][2], a[dt][3]));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = half * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(xs + r * AB_PITCH + ch * 8);
+            if (r0 + r < L) *reinterpret_cast<uint4*>(gbase + (long)(r0 + r) * ld + ch * 8) = v;
+        }
+    };
+
     // ---- stage Q, K, V, dO (rows >= L zero-filled) and lse ----
-    for (int idx = threadIdx.x; idx < LP * 8 * 4; idx += AB_THREADS) {
-        const int which = idx / (LP * 8);
-        const int rem = idx - which * (LP * 8);
-        const int row = rem >> 3, ch = rem & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < L)
-            v = which < 3 ? *reinterpret_cast<const uint4*>(qb + (long)row * ld + which * C + ch * 8)
-                          : *reinterpret_cast<const uint4*>(dob + (long)row * C + ch * 8);
-        *reinterpret_cast<uint4*>(Qs + which * (LP * AB_PITCH) + row * AB_PITCH + ch * 8) = v;
-    }
+    stage_tiles<4, (LP * 8 * 4 + 2 * AB_THREADS - 1) / (2 * AB_THREADS), LP>(Qs, qb, ld, C, dob, L);
     for (int q = threadIdx.x; q < LP; q += AB_THREADS) lse_s[q] = q < L ? lser[q] : 0.f;
     __syncthreads();
     const float scale = 0.125f;
@@ -284,13 +416,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
                     acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Ks, dt, ta, tb, fr, fq), sf, acc[dt], 0, 0, 0);
             }
         }
-        if (query < L) {
-            bf16_t* row = dqb + (long)query * ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(row + dt * 16 + fq * 4) =
-                    make_uint2(pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3]));
-        }
+        store_tile(acc, dqb, q0);
     }
     __syncthreads();  // delta[] complete
 
@@ -349,17 +475,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
                 ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_trfrag(Qs, dt, ta, tb, fr, fq), sf, ak[dt], 0, 0, 0);  // dK^T[d,key]
             }
         }
-        if (key < L) {
-            bf16_t* vrow = dvb + (long)key * ld;
-            bf16_t* krow = dkb + (long)key * ld;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                *reinterpret_cast<uint2*>(vrow + dt * 16 + fq * 4) =
-                    make_uint2(pack2bf(av[dt][0], av[dt][1]), pack2bf(av[dt][2], av[dt][3]));
-                *reinterpret_cast<uint2*>(krow + dt * 16 + fq * 4) =
-                    make_uint2(pack2bf(ak[dt][0], ak[dt][1]), pack2bf(ak[dt][2], ak[dt][3]));
-            }
-        }
+        store_tile(av, dvb, k0);
+        store_tile(ak, dkb, k0);
     }
 }
 
@@ -390,9 +507,19 @@ static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, 
 }
 
 template <int NT>
+static int launch_fwd3(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
+                       hipStream_t s) {
+    constexpr size_t lds = (size_t)3 * NT * 16 * AB_PITCH * 2;
+    hipLaunchKernelGGL(attn_fwd3_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, out, lse, nseq, L,
+                       heads, causal);
+    NEAT_LAUNCH_CHECK("neat_attn_fwd");
+    return NEAT_OK;
+}
+
+template <int NT>
 static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq, int L,
                       int heads, int causal, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * NT * 16 * AB_PITCH * 2 + 2 * NT * 16 * 4;
+    constexpr size_t lds = (size_t)4 * NT * 16 * AB_PITCH * 2 + 2 * NT * 16 * 4 + (size_t)AB_WAVES * 16 * AB_PITCH * 2;
     static bool attr = false;
     if (!attr) {
         int rc = check_hip(hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>,
@@ -416,9 +543,9 @@ extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int
     NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
-        case 1: return launch_fwd<1>(qkv, out, lse, nseq, L, heads, causal, s);
-        case 4: return launch_fwd<4>(qkv, out, lse, nseq, L, heads, causal, s);
-        case 5: return launch_fwd<5>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 1: return launch_fwd3<1>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 4: return launch_fwd3<4>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 5: return launch_fwd3<5>(qkv, out, lse, nseq, L, heads, causal, s);
         case 13: return launch_fwd<13>(qkv, out, lse, nseq, L, heads, causal, s);
         case 17: return launch_fwd<17>(qkv, out, lse, nseq, L, heads, causal, s);
         default: return set_error(NEAT_ERR_SHAPE, "neat_attn_fwd: sequence length %d > 272 unsupported", L);
