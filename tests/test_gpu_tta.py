@@ -254,6 +254,35 @@ def test_autograd_api_and_torch_optimizer():
     assert rel_l2(_flat_ln(model_b), _flat_ln(model_a)) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["ViT-B-16", "ViT-L-14"])
+def test_other_clip_configs_match_oracle(name):
+    """BASELINE configs 3/5 use ViT-L-14 / ViT-B-16: other widths (768 / 1024), longer vision sequences (197 / 257
+    tokens -> the one-wave attention kernels), 24 vision layers, D = 768.  Encoders and one full TTA step vs the
+    fp32 oracle (parity of the oracle itself is pinned on ViT-B-32; these configs share every formula)."""
+    model, sd = _model(name, 3)
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    toks = synth.synth_caption_sets(3, t["context_length"], t["vocab_size"], 11)
+    img = synth.synth_images(2, cfg["vision_cfg"]["image_size"], 12)
+    with torch.no_grad():
+        fi = model.encode_image(img.to(DEV), normalize=True).cpu()
+        ft = model.encode_text(toks[0].to(DEV), normalize=True).cpu()
+    assert min_cosine(fi, O.encode_image_fwd(sd, img)) >= 0.999
+    assert min_cosine(ft, O.encode_text_fwd(sd, toks[0])[0]) >= 0.999
+    # one adaptation step
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+    G = torch.nn.functional.normalize(torch.randn(7, cfg["embed_dim"], generator=torch.Generator().manual_seed(1)), dim=-1)
+    losses, idx, S = T.tta_step(model, opt, [x.to(DEV) for x in toks], G.to(DEV), 0.03, 0.07)
+    st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
+    lo, io, So, _, _ = O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)
+    assert abs(float(losses.sum()) - float(lo.sum())) <= 2e-3 * abs(float(lo.sum()))
+    assert float((S.cpu() - So).abs().max()) < 5e-3
+    flat_o = torch.cat([sd[k].flatten() for k in O.adapted_param_names(sd)])
+    assert rel_l2(_flat_ln(model), flat_o) < 1e-3
+
+
 def test_video_pooling_matches_oracle():
     model, sd = _model("neat-tiny", 0)
     clips = synth.synth_images(3 * 4, 32, 5).view(3, 4, 3, 32, 32)
