@@ -151,6 +151,14 @@ int neat_topk_rows(const float* scores, long ld_row, long ld_col, int R, int Nco
 /* recall[r] = |topk(r) ∩ positives(r)| / |positives(r)| with positives a strided uint8/bool matrix */
 int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, long ld_row, long ld_col, int R,
                           int Ncol, int k, float* recall, void* stream);
+/* median-rank support, evaluation/retrieval.py:186-214: rank[r] (1-based, scores descending, equal scores by
+ * index) of the best-ranked positive of row r; 0 if the row has none.  scores / pos strided like neat_topk_rows. */
+int neat_best_positive_rank(const float* scores, long ld_row, long ld_col, const uint8_t* pos, long pld_row,
+                            long pld_col, int R, int Ncol, int32_t* rank, void* stream);
+/* multiple-choice scoring, evaluation/mcq.py:92-97, :199-205: img f32 [B,D], txt f32 [nopt,B,D] ->
+ * logits f32 [B,nopt] = einsum('bf,nbf->bn') (may be NULL), pred i32 [B] = argmax_n (first max) */
+int neat_mcq_scores(const float* img, const float* txt, float* logits, int32_t* pred, int B, int nopt, int D,
+                    void* stream);
 /* fp32 similarity GEMM C[M,N] = A[M,K] B[N,K]^T (exact fp32 FMA chain; feeds argmax/top-k) */
 int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
 

@@ -160,6 +160,79 @@ __global__ __launch_bounds__(64) void recall_cols_kernel(const int32_t* __restri
     recall[r] = tp / n;
 }
 
+
+// ---- median-rank support, evaluation/retrieval.py:186-214: rank (1-based, descending scores) of the best-ranked
+// positive of every row; equal scores are ordered by index, like the top-k kernels.  0 = row has no positive.
+__global__ __launch_bounds__(256) void best_positive_rank_kernel(const float* __restrict__ scores, long ld_row,
+                                                                 long ld_col, const uint8_t* __restrict__ pos,
+                                                                 long pld_row, long pld_col, int R, int Ncol,
+                                                                 int32_t* __restrict__ rank) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int sc[4];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* srow = scores + (long)r * ld_row;
+    const uint8_t* prow = pos + (long)r * pld_row;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < Ncol; c += 256) {
+        if (prow[(long)c * pld_col]) {
+            const float v = srow[(long)c * ld_col];
+            if (bi == 0x7fffffff || v > best) { best = v; bi = c; }   // c ascending per thread: first max kept
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (si[w] != 0x7fffffff && (bi == 0x7fffffff || sv[w] > best || (sv[w] == best && si[w] < bi))) { best = sv[w]; bi = si[w]; }
+    if (bi == 0x7fffffff) {
+        if (threadIdx.x == 0) rank[r] = 0;
+        return;
+    }
+    int cnt = 0;
+    for (int c = threadIdx.x; c < Ncol; c += 256) {
+        const float v = srow[(long)c * ld_col];
+        cnt += (v > best || (v == best && c < bi)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) sc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[r] = 1 + sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+// ---- multiple-choice scoring, evaluation/mcq.py:92-97 and :199-205: logits[b,n] = <img[b], txt[n,b]>,
+// pred[b] = argmax_n (first max).  One wavefront per image.
+__global__ __launch_bounds__(256) void mcq_scores_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                         float* __restrict__ logits, int32_t* __restrict__ pred, int B,
+                                                         int nopt, int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* ib = img + (long)b * D;
+    float bestv = -INFINITY;
+    int besti = 0;
+    for (int n = 0; n < nopt; ++n) {
+        const float* tb = txt + ((long)n * B + b) * D;
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc = fmaf(ib[d], tb[d], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0 && logits) logits[(long)b * nopt + n] = acc;
+        if (acc > bestv) { bestv = acc; besti = n; }
+    }
+    if (lane == 0) pred[b] = besti;
+}
+
 static inline int topk_nsplit(int Ncol) {
     int s = Ncol / 512;
     return s < 1 ? 1 : (s > 64 ? 64 : s);
@@ -218,5 +291,25 @@ extern "C" int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, lon
         hipLaunchKernelGGL(recall_cols_kernel, dim3(cdiv(R, 64)), dim3(64), 0, s, idx, pos, ld_col, R, Ncol, k, recall);
     }
     NEAT_LAUNCH_CHECK("neat_recall_from_topk");
+    return NEAT_OK;
+}
+
+extern "C" int neat_best_positive_rank(const float* scores, long ld_row, long ld_col, const uint8_t* pos, long pld_row,
+                                       long pld_col, int R, int Ncol, int32_t* rank, void* stream) {
+    NEAT_REQUIRE(scores && pos && rank, NEAT_ERR_ARG, "neat_best_positive_rank: null pointer");
+    NEAT_REQUIRE(R > 0 && Ncol > 0, NEAT_ERR_SHAPE, "neat_best_positive_rank: empty matrix");
+    hipLaunchKernelGGL(best_positive_rank_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, scores, ld_row, ld_col, pos,
+                       pld_row, pld_col, R, Ncol, rank);
+    NEAT_LAUNCH_CHECK("neat_best_positive_rank");
+    return NEAT_OK;
+}
+
+extern "C" int neat_mcq_scores(const float* img, const float* txt, float* logits, int32_t* pred, int B, int nopt, int D,
+                               void* stream) {
+    NEAT_REQUIRE(img && txt && pred, NEAT_ERR_ARG, "neat_mcq_scores: null pointer");
+    NEAT_REQUIRE(B > 0 && nopt > 0 && D > 0, NEAT_ERR_SHAPE, "neat_mcq_scores: bad shape");
+    hipLaunchKernelGGL(mcq_scores_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, img, txt, logits, pred, B,
+                       nopt, D);
+    NEAT_LAUNCH_CHECK("neat_mcq_scores");
     return NEAT_OK;
 }

@@ -1,5 +1,5 @@
 """Retrieval scoring on HIP kernels, with the reference's function names and semantics
-(reference src/evaluation/retrieval.py:186-214, 219-257, 280-333)."""
+(reference src/evaluation/retrieval.py:11-89, 186-214, 219-257, 259-278, 280-333)."""
 from __future__ import annotations
 
 import torch
@@ -28,14 +28,81 @@ def batchify(func, X, Y, batch_size, device, *args, **kwargs):
     return torch.cat(results)
 
 
-def recall_metrics(scores, positive_pairs, recall_k_list=(1, 5, 10)):
-    """The six recall numbers of evaluate_model_with_similarity (retrieval.py:243-250) in one pass per
-    direction and k, whole matrix at once."""
+def median_rank(scores, positive_pairs):
+    """retrieval.py:186-214: median over rows of the (1-based) rank of the best-ranked positive; rows without a
+    positive are dropped; ``torch.median`` semantics (lower middle element).  The reference sorts every row and
+    scatters ranks with a Python loop; here one kernel counts, per row, the scores that beat the best positive."""
+    ranks = ops.best_positive_rank(scores, positive_pairs).cpu().tolist()
+    ranks = sorted(r for r in ranks if r > 0)
+    if not ranks:
+        return float("nan")
+    return float(ranks[(len(ranks) - 1) // 2])
+
+
+def recall_metrics(scores, positive_pairs, recall_k_list=(1, 5, 10), with_median_rank=False):
+    """The recall numbers of evaluate_model_with_similarity (retrieval.py:243-250), one pass per direction and
+    k over the whole matrix, plus (optionally) the two medR entries (:254-255)."""
     metrics = {}
     for k in recall_k_list:
         metrics[f"image_retrieval_recall@{k}"] = (recall_at_k(scores, positive_pairs, k) > 0).float().mean().item()
         metrics[f"text_retrieval_recall@{k}"] = (recall_at_k(scores.T, positive_pairs.T, k) > 0).float().mean().item()
+    if with_median_rank:
+        metrics["image_retrieval_medR"] = median_rank(scores, positive_pairs)
+        metrics["text_retrieval_medR"] = median_rank(scores.T, positive_pairs.T)
     return metrics
+
+
+def dataloader_with_indices(dataloader):
+    """retrieval.py:259-278"""
+    start = 0
+    for batch in dataloader:
+        end = start + len(batch[0])
+        yield (*batch, torch.arange(start, end))
+        start = end
+
+
+def evaluate_model(model, dataloader, args, tokenizer, recall_k_list=(1, 5, 10)):
+    """retrieval.py:11-89 ("offline" evaluation): re-encode every image and caption with the current (adapted)
+    parameters, score all pairs, recall@k both ways and medR.  Embeddings stay on the GPU (the reference moves
+    them to the CPU and multiplies there); the similarity is the exact-fp32 GEMM that also feeds top-k."""
+    device = getattr(args, "device", "cuda")
+    img_emb, txt_emb, texts_image_index = [], [], []
+    with torch.no_grad():
+        for batch_images, batch_texts, inds in dataloader_with_indices(dataloader):
+            toks = tokenizer([text for texts in batch_texts for text in texts]).to(device)
+            if toks.dtype != torch.int64:
+                toks = toks.long()
+            img_emb.append(model.encode_image(batch_images.to(device), normalize=True))
+            txt_emb.append(model.encode_text(toks, normalize=True))
+            texts_image_index.extend(int(ind) for ind, texts in zip(inds, batch_texts) for _ in texts)
+    images_emb = torch.cat(img_emb).contiguous()
+    texts_emb = torch.cat(txt_emb).contiguous()
+    scores = ops.gemm_f32_nt(texts_emb, images_emb)
+    positive_pairs = torch.zeros_like(scores, dtype=torch.bool)
+    positive_pairs[torch.arange(len(scores), device=scores.device),
+                   torch.as_tensor(texts_image_index, device=scores.device)] = True
+    return recall_metrics(scores, positive_pairs, recall_k_list, with_median_rank=True)
+
+
+def retrieval_eval(model, data, args, scores, tokenizer=None):
+    """retrieval.py:91-183: the result keys the reference's CLI logs, for the datasets present in ``data``
+    (objects with a ``.dataloader``)."""
+    results = {}
+
+    def put(prefix, m):
+        for d, key in (("t2i", "image_retrieval"), ("i2t", "text_retrieval")):
+            for k in (1, 5, 10):
+                results[f"{prefix}-{d}-R@{k}"] = m[f"{key}_recall@{k}"]
+
+    video = getattr(args, "video", False)
+    plain, negated = ("msrvtt-retrieval", "msrvtt-negated-retrieval") if video else ("coco-retrieval", "coco-negated-retrieval")
+    stem = "msrvtt" if video else "coco"
+    if plain in data:
+        put(stem, evaluate_model(model, data[plain].dataloader, args, tokenizer))
+    if negated in data:
+        put(f"online-{stem}-negated", evaluate_model_with_similarity(data[negated].dataloader, args, scores))
+        put(f"offline-{stem}-negated", evaluate_model(model, data[negated].dataloader, args, tokenizer))
+    return results
 
 
 def evaluate_model_with_similarity(dataloader, args, scores, recall_k_list=(1, 5, 10), texts_image_index=None):
@@ -52,4 +119,4 @@ def evaluate_model_with_similarity(dataloader, args, scores, recall_k_list=(1, 5
     positive_pairs = torch.zeros_like(scores, dtype=torch.bool)
     positive_pairs[torch.arange(len(scores), device=scores.device),
                    torch.as_tensor(texts_image_index, device=scores.device)] = True
-    return recall_metrics(scores, positive_pairs, recall_k_list)
+    return recall_metrics(scores, positive_pairs, recall_k_list, with_median_rank=True)

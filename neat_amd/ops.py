@@ -317,6 +317,31 @@ def recall_from_topk(idx, positive_pairs):
     return out
 
 
+def best_positive_rank(scores, positive_pairs):
+    """int32 [R]: 1-based rank of the best-ranked positive per row (0: no positive).  Accepts transposed views."""
+    if positive_pairs.dtype == torch.bool:
+        positive_pairs = positive_pairs.view(torch.uint8)
+    if not scores.is_cuda or scores.dtype != f32 or positive_pairs.dtype != torch.uint8 or not positive_pairs.is_cuda:
+        raise RuntimeError("best_positive_rank: expected float32 scores and bool/uint8 positives on the GPU")
+    R, N = scores.shape
+    sr, sc = scores.stride()
+    pr, pc = positive_pairs.stride()
+    out = torch.empty(R, dtype=i32, device=scores.device)
+    lib.call("neat_best_positive_rank", scores.data_ptr(), sr, sc, positive_pairs.data_ptr(), pr, pc, R, N, _p(out),
+             _stream())
+    return out
+
+
+def mcq_scores(image_features, text_features):
+    """image_features f32 [B,D], text_features f32 [n,B,D] -> (logits [B,n], pred int32 [B])."""
+    n, B, D = text_features.shape
+    logits = torch.empty(B, n, dtype=f32, device=image_features.device)
+    pred = torch.empty(B, dtype=i32, device=image_features.device)
+    lib.call("neat_mcq_scores", _p(image_features.contiguous(), f32, "image_features"),
+             _p(text_features.contiguous(), f32, "text_features"), _p(logits), _p(pred), B, n, D, _stream())
+    return logits, pred
+
+
 def gemm_f32_nt(A, B):
     M, K = A.shape
     N = B.shape[0]

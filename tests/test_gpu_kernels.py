@@ -401,6 +401,49 @@ def test_topk_full_size_properties():
         assert (cnt_ge == 10).all()            # continuous scores: no ties
 
 
+def test_median_rank_golden_and_ties():
+    """medR against the reference's own numbers (golden), and the per-row ranks against the oracle's stable sort on
+    a matrix full of ties, both directions (the transposed direction reads the matrix as a strided view)."""
+    from neat_amd.evaluation import retrieval as R
+    z = load_golden("recall")
+    scores = torch.from_numpy(z["scores"])
+    owner = torch.from_numpy(z["owner"]).long()
+    pos = torch.zeros(scores.shape, dtype=torch.bool)
+    pos[torch.arange(len(owner)), owner] = True
+    assert R.median_rank(scores.to(DEV), pos.to(DEV)) == float(z["medr_t2i"])
+    assert R.median_rank(scores.to(DEV).T, pos.to(DEV).T) == float(z["medr_i2t"])
+    tie = torch.randint(0, 4, (300, 777), generator=g(5)).float()
+    tp = torch.rand(300, 777, generator=g(6)) < 0.01
+    tp[7] = False                                            # a row without positives
+    for sc, pp in ((tie, tp), (tie.t(), tp.t())):
+        got = ops.best_positive_rank(sc.to(DEV) if sc.is_contiguous() else tie.to(DEV).T,
+                                     pp.to(DEV) if pp.is_contiguous() else tp.to(DEV).T).cpu().long()
+        order = torch.sort(-sc.double(), dim=1, stable=True)[1]
+        ranks = torch.empty_like(order)
+        ranks.scatter_(1, order, torch.arange(sc.shape[1]).expand_as(order))
+        ref = (ranks + 1).masked_fill(~pp, 1 << 30).min(1)[0]
+        ref[ref == (1 << 30)] = 0
+        assert torch.equal(got, ref)
+        assert R.median_rank(sc.to(DEV) if sc.is_contiguous() else tie.to(DEV).T,
+                             pp.to(DEV) if pp.is_contiguous() else tp.to(DEV).T) == O.median_rank(sc, pp)
+
+
+def test_mcq_scores():
+    """einsum('bf,nbf->bn') + argmax (reference evaluation/mcq.py:92-97), incl. a tie -> first option."""
+    B, n, D = 67, 4, 512
+    img = _unit(B, D, 1)
+    txt = torch.stack([_unit(B, D, 10 + i) for i in range(n)])
+    txt[2, 5] = txt[1, 5]                                    # options 1 and 2 tie for image 5
+    img[5] = txt[1, 5]
+    logits, pred = ops.mcq_scores(img.to(DEV), txt.to(DEV))
+    ref = torch.einsum("bf,nbf->bn", img, txt)
+    assert float((logits.cpu() - ref).abs().max()) < 1e-5
+    assert int(pred[5]) == 1
+    ok = pred.cpu().long() == ref.argmax(1)
+    margin = ref.topk(2, dim=1)[0]
+    assert (ok | ((margin[:, 0] - margin[:, 1]) < 1e-5)).all()
+
+
 def test_gemm_f32_nt():
     A = torch.randn(300, 512, generator=g(1)); B = torch.randn(77, 512, generator=g(2))
     Cm = ops.gemm_f32_nt(A.to(DEV), B.to(DEV))

@@ -283,6 +283,70 @@ def test_other_clip_configs_match_oracle(name):
     assert rel_l2(_flat_ln(model), flat_o) < 1e-3
 
 
+class _ListLoader:
+    def __init__(self, batches, n):
+        self.batches, self.dataset = batches, list(range(n))
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def _fake_tokenizer(ctx, vocab):
+    """Deterministic stand-in for the BPE tokenizer: strings of integers -> token rows (SOT ... EOT, zero padded)."""
+    def tok(texts):
+        out = torch.zeros(len(texts), ctx, dtype=torch.int64)
+        for i, t in enumerate(texts):
+            ids = [int(x) % (vocab - 3) + 1 for x in t.split()][: ctx - 2]
+            row = [vocab - 2] + ids + [vocab - 1]
+            out[i, : len(row)] = torch.tensor(row)
+        return out
+    return tok
+
+
+def test_offline_eval_and_mcq_match_oracle():
+    """evaluate_model (offline retrieval, reference evaluation/retrieval.py:11-89) and the MCQ
+    scorers (evaluation/mcq.py:10-217) on the tiny model against the oracle encoders + the reference formulas."""
+    from neat_amd.evaluation import mcq as MQ, retrieval as R
+    model, sd = _model("neat-tiny", 0)
+    cfg = synth.get_cfg("neat-tiny")
+    tok = _fake_tokenizer(cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"])
+    gen = torch.Generator().manual_seed(3)
+    n_img, per = 12, 3
+    imgs = synth.synth_images(n_img, 32, 21)
+    caps = [[" ".join(str(int(x)) for x in torch.randint(0, 400, (6,), generator=gen)) for _ in range(per)]
+            for _ in range(n_img)]
+    batches = [(imgs[i:i + 4], caps[i:i + 4]) for i in range(0, n_img, 4)]
+    args = types.SimpleNamespace(device=DEV, batch_size=4, video=False)
+    got = R.evaluate_model(model, _ListLoader(batches, n_img), args, tok)
+    fi = O.encode_image_fwd(sd, imgs)
+    ft = O.encode_text_fwd(sd, tok([c for cs in caps for c in cs]))[0]
+    scores = ft @ fi.t()
+    pos = torch.zeros_like(scores, dtype=torch.bool)
+    pos[torch.arange(n_img * per), torch.arange(n_img * per) // per] = True
+    ref = O.recall_metrics(scores, pos)
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 1.0 / n_img + 1e-6, k       # a near-tie may flip one row under bf16 encoders
+    assert abs(got["image_retrieval_medR"] - O.median_rank(scores, pos)) <= 1
+    assert abs(got["text_retrieval_medR"] - O.median_rank(scores.t(), pos.t())) <= 1
+    # MCQ: 4 options per image, option lists are [options][batch]
+    opts = [[caps[i][0] for i in range(n_img)]] + [
+        [" ".join(str(int(x)) for x in torch.randint(0, 400, (6,), generator=gen)) for _ in range(n_img)] for _ in range(3)]
+    answers = torch.randint(0, 4, (n_img,), generator=gen)
+    types_ = [("positive", "negative", "hybrid")[i % 3] for i in range(n_img)]
+    mb = [(imgs[i:i + 6], [o[i:i + 6] for o in opts], answers[i:i + 6], types_[i:i + 6]) for i in range(0, n_img, 6)]
+    m = MQ.evaluate_model(model, _ListLoader(mb, n_img), args, tok, is_synthetic=True)   # answers at any index
+    ftxt = torch.stack([O.encode_text_fwd(sd, tok(o))[0] for o in opts])
+    logits = torch.einsum("bf,nbf->bn", fi, ftxt)
+    margin = logits.topk(2, dim=1)[0]
+    clear = (margin[:, 0] - margin[:, 1]) > 2e-2
+    ref_acc = float((logits.argmax(1) == answers).float().mean())
+    assert abs(m["total_accuracy"] - ref_acc) <= float((~clear).sum()) / n_img + 1e-6
+    assert sum(m["predictions_by_type"].values()) == n_img
+    b2 = [(imgs[i:i + 6], [o[i:i + 6] for o in opts[:2]], answers[i:i + 6] % 2) for i in range(0, n_img, 6)]
+    mb2 = MQ.evaluate_binary_mcq_model(model, _ListLoader(b2, n_img), args, tok)
+    assert 0.0 <= mb2["total_accuracy"] <= 1.0
+
+
 def test_video_pooling_matches_oracle():
     model, sd = _model("neat-tiny", 0)
     clips = synth.synth_images(3 * 4, 32, 5).view(3, 4, 3, 32, 32)
