@@ -67,6 +67,11 @@ def text_tower_flops_per_row_step(cfg, L):
     return 4 * fwd + 3 * bwd
 
 
+def _dbg(msg):
+    if os.environ.get("NEAT_BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', 0)}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -74,16 +79,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         a.gpus = world
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsal of N ranks on fewer GPUs (NEAT_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NEAT_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from neat_amd import lib, open_clip as oc, ops, synth
     from neat_amd import train_TTA as T
     from neat_amd.optim import AdamW
     lib.load()
 
+    _dbg('library loaded')
     cfg = synth.get_cfg(a.model)
     tcfg = cfg["text_cfg"]
     L = tcfg["context_length"]
@@ -93,6 +105,7 @@ def main():
     params, _ = oc.collect_params(model, False)
     opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
 
+    _dbg('model ready')
     # ---- Phase A: gallery (timed separately; each rank encodes its shard, then all-gather) ----
     n_img = a.gallery
     lo, hi = T._shard(n_img, world, rank)
@@ -114,6 +127,7 @@ def main():
     gallery_s = time.perf_counter() - t0
     G = T._all_gather_rows(G_local, n_img, world) if world > 1 else G_local
 
+    _dbg('gallery done')
     # ---- synthetic caption batches, resident in HBM ----
     nb = a.steps + a.warmup
     B = a.batch
@@ -138,9 +152,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _dbg('batches ready')
+    if os.environ.get('NEAT_BENCH_DEBUG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=True)
     for i in range(a.warmup):
         run_batch(i)
+        _dbg(f'warmup {i} done')
     barrier()
+    _dbg('timed region starts')
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(a.warmup, nb):
@@ -148,6 +168,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    _dbg('timed region done')
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

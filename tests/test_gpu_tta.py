@@ -283,6 +283,56 @@ def test_other_clip_configs_match_oracle(name):
     assert rel_l2(_flat_ln(model), flat_o) < 1e-3
 
 
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0 on the 1-GPU box
+    try:
+        model, _ = _model("neat-tiny", 0)
+        oc.freeze_parameters(model, False)
+        params, _ = oc.collect_params(model, False)
+        opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+        cfg = synth.get_cfg("neat-tiny")["text_cfg"]
+        toks = synth.synth_caption_sets(9, cfg["context_length"], cfg["vocab_size"], 77)
+        G = torch.nn.functional.normalize(torch.randn(12, 512, generator=torch.Generator().manual_seed(5)), dim=-1).to(DEV)
+        lo, hi = T._shard(9, world, rank)
+        local = [x[lo:hi].contiguous().to(DEV) for x in toks]
+        for _ in range(2):
+            losses, idx, S = T.tta_step(model, opt, local, G, 0.03, 0.07, world, rank)
+        S_all = T._all_gather_rows(S, 9, world)
+        torch.save(dict(losses=losses.cpu(), S=S_all.cpu(), params=_flat_ln(model)), os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_step_equals_single_gpu(tmp_path):
+    """SURVEY §8e equality requirement on the real kernels: two ranks (uneven row shards 5 + 4, gloo rendezvous,
+    both on cuda:0) must reproduce the single-process step on the same global batch -- losses, LN parameters and
+    score rows -- up to fp32 reduction order."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
+    model, _ = _model("neat-tiny", 0)
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+    cfg = synth.get_cfg("neat-tiny")["text_cfg"]
+    toks = [x.to(DEV) for x in synth.synth_caption_sets(9, cfg["context_length"], cfg["vocab_size"], 77)]
+    G = torch.nn.functional.normalize(torch.randn(12, 512, generator=torch.Generator().manual_seed(5)), dim=-1).to(DEV)
+    for _ in range(2):
+        losses, idx, S = T.tta_step(model, opt, toks, G, 0.03, 0.07)
+    assert torch.equal(r0["params"], r1["params"])                       # ranks stay in lock step
+    assert rel_l2(r0["params"], _flat_ln(model)) < 2e-5
+    torch.testing.assert_close(r0["losses"], losses.cpu(), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(r0["S"], S.cpu(), rtol=0, atol=2e-3)
+
+
 class _ListLoader:
     def __init__(self, batches, n):
         self.batches, self.dataset = batches, list(range(n))
