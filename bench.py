@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--tta-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=128, help="caption rows in the CPU-oracle sample")
+    ap.add_argument("--no-packed", action="store_true",
+                    help="skip the extra (non-headline) measurement with model.pack_tokens = True")
     ap.add_argument("--skip-gallery-encode", action="store_true",
                     help="profiling aid: random unit-norm gallery features instead of Phase A, so that a "
                          "rocprofv3 summary holds text-tower launches only")
@@ -195,6 +197,28 @@ def main():
                     mfma_frac=round(tfs / MFMA_BF16_PEAK_TFLOPS, 4),
                     step_tflops=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12, 1))
 
+    # ---- extra, NOT the headline: the same batches with the opt-in packed text batches (positions after EOT
+    # dropped; identical outputs, tests/test_gpu_tta.py::test_packed_tokens_equal_full_length) ----
+    packed = None
+    if not a.no_packed:
+        model.pack_tokens = True
+        run_batch(0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, nb):
+            run_batch(i)
+        barrier()
+        dtp = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dtp], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtp = float(tmax.item())
+        model.pack_tokens = False
+        ntok = sum(float((b[0].argmax(dim=-1) + 1).float().mean()) for b in batches) / len(batches)
+        packed = dict(value=round(pairs / dtp, 2), unit="pairs/s", ms_per_step=round(dtp / a.steps * 1e3, 3),
+                      mean_tokens_per_caption=round(ntok, 2), context_length=L,
+                      note="opt-in model.pack_tokens: text tower runs positions 0..EOT only; same outputs")
+
     # recall@1 on the produced score rows (synthetic ground truth: caption r <-> image r % N)
     from neat_amd.evaluation import retrieval as R
     rows = torch.arange(B * nb, device=dev)
@@ -211,6 +235,8 @@ def main():
                            parallelism=f"dp{world}"),
                gallery_images_per_s=None if a.skip_gallery_encode else round(n_img / gallery_s, 1), recall_at_1_t2i=r1,
                last_losses=[round(x, 4) for x in losses.tolist()], roofline=roofline)
+    if packed is not None:
+        out["packed_tokens"] = packed
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, cfg)

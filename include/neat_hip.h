@@ -75,13 +75,16 @@ int neat_gemm_bf16(const uint16_t* A, const uint16_t* Wp, const float* bias, con
                    void* stream);
 
 /* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
-/* qkv bf16 [nseq*L, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [nseq*L, C];
- * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL). */
-int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads,
-                  int causal, void* stream);
-/* dout bf16 [nseq*L, C] -> dqkv bf16 [nseq*L, 3*C] */
-int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq,
-                  int L, int heads, int causal, void* stream);
+/* qkv bf16 [rows, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [rows, C];
+ * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL).
+ * cu_seqlens == NULL: fixed-length batch, rows = nseq*L, sequence s owns rows s*L .. s*L+L-1.
+ * cu_seqlens i32 [nseq+1] (packed batch, see neat_pack_plan): sequence s owns rows cu[s] .. cu[s+1]-1, L is the
+ * maximum length (<= 80) and the row pitch of lse. */
+int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens, int nseq, int L,
+                  int heads, int causal, void* stream);
+/* dout bf16 [rows, C] -> dqkv bf16 [rows, 3*C]; L <= 80 */
+int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv,
+                  const int32_t* cu_seqlens, int nseq, int L, int heads, int causal, void* stream);
 
 /* ---- text embedding: nn.Embedding + positional add, open_clip/model.py:272-274 ---- */
 int neat_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* x, int nseq,
@@ -89,9 +92,21 @@ int neat_embed_fwd(const int64_t* tokens, const float* tok_emb, const float* pos
 /* argmax over each token row (EOT position), open_clip/transformer.py:555-558; first max wins */
 int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int L, void* stream);
 
+/* ---- packed text batches.  No reference counterpart as code: the reference encodes all 77 positions
+ *      (open_clip/model.py:269-286); with its causal mask (transformer.py:655-661) and EOT pooling (:555-558)
+ *      positions after the EOT token can neither influence the pooled feature nor receive gradient, so they
+ *      may be dropped without changing any output of the path. ---- */
+/* tokens i64 [nseq, L] -> eot i32 [nseq] (argmax, first max), cu_seqlens i32 [nseq+1] = exclusive prefix sums of
+ * eot+1 (cu[nseq] = packed row count).  nseq <= 12000. */
+int neat_pack_plan(const int64_t* tokens, int32_t* eot, int32_t* cu_seqlens, int nseq, int L, void* stream);
+/* x f32 [cu[nseq], C]: row cu[s]+p = tok_emb[tokens[s,p]] + pos_emb[p] for p <= eot[s] */
+int neat_embed_packed_fwd(const int64_t* tokens, const int32_t* cu_seqlens, const float* tok_emb,
+                          const float* pos_emb, float* x, int nseq, int L, int C, int vocab, void* stream);
+
 /* ---- pooled head: ln_final/ln_post on the pooled row -> @ projection -> F.normalize
  *      open_clip/model.py:278-286 (text), open_clip/transformer.py:538-542 + model.py:267 (vision) ---- */
 /* x f32 [nseq*L, C]; row index per sequence (NULL -> row 0 = class token); proj f32 [C, D].
+ * L == 0: row_idx holds ABSOLUTE rows of x (packed batches).
  * Outputs: feat f32 [nseq, D] (normalised iff normalize), and for backward: xe f32 [nseq,C] (pooled rows),
  * mean/rstd [nseq], nrm [nseq] (L2 norm before clamping).  Backward-only outputs may be NULL. */
 int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,

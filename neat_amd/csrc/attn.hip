@@ -227,7 +227,8 @@ __device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long 
 template <int NT>
 __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv,
                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                               int nseq, int L, int heads, int causal) {
+                                                               const int32_t* __restrict__ cu, int nseq, int Lmax,
+                                                               int heads, int causal) {
     constexpr int LP = NT * 16;
     constexpr int NP = (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,7 +241,10 @@ __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __r
     const int C = heads * HD;
     const long ld = 3L * C;
     const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
-    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
+    // packed batches: rows cu[s] .. cu[s+1]-1; fixed-length batches: rows s*Lmax .. s*Lmax+Lmax-1
+    const long r0 = cu ? (long)cu[s] : (long)s * Lmax;
+    const int L = cu ? cu[s + 1] - cu[s] : Lmax;
+    const bf16_t* qb = qkv + r0 * ld + h * HD;
 
     stage_tiles<3, (LP * 8 * 3 + AB_THREADS - 1) / AB_THREADS, LP>(Qs, qb, ld, C, nullptr, L);
     __syncthreads();
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __r
                 sum += st[kt][r];
             }
         sum = xor_sum_16_32(sum);
-        if (lse && fq == 0 && query < L) lse[((long)s * heads + h) * L + query] = mx + __logf(sum);
+        if (lse && fq == 0 && query < L) lse[((long)s * heads + h) * Lmax + query] = mx + __logf(sum);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __r
         for (int half = 0; half < 2; ++half) {
             const int r = half * 8 + (lane >> 3), ch = lane & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(Qs + (q0 + r) * AB_PITCH + ch * 8);
-            if (q0 + r < L) *reinterpret_cast<uint4*>(out + ((long)s * L + q0 + r) * C + h * HD + ch * 8) = v;
+            if (q0 + r < L) *reinterpret_cast<uint4*>(out + (r0 + q0 + r) * C + h * HD + ch * 8) = v;
         }
     }
 }
@@ -317,8 +321,9 @@ template <int NT>
 __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ dout,
                                                               const float* __restrict__ lse,
-                                                              bf16_t* __restrict__ dqkv, int nseq, int L, int heads,
-                                                              int causal) {
+                                                              bf16_t* __restrict__ dqkv,
+                                                              const int32_t* __restrict__ cu, int nseq, int Lmax,
+                                                              int heads, int causal) {
     constexpr int LP = NT * 16;
     constexpr int NP = (NT + 1) / 2;  // pairs of 16-wide tiles = MFMA k-steps over a summed sequence index
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,10 +341,12 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
     const int C = heads * HD;
     const long ld = 3L * C;
     const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
-    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
-    const bf16_t* dob = dout + (long)s * L * C + h * HD;
-    const float* lser = lse + ((long)s * heads + h) * L;
-    bf16_t* dqb = dqkv + (long)s * L * ld + h * HD;
+    const long r0 = cu ? (long)cu[s] : (long)s * Lmax;
+    const int L = cu ? cu[s + 1] - cu[s] : Lmax;
+    const bf16_t* qb = qkv + r0 * ld + h * HD;
+    const bf16_t* dob = dout + r0 * C + h * HD;
+    const float* lser = lse + ((long)s * heads + h) * Lmax;
+    bf16_t* dqb = dqkv + r0 * ld + h * HD;
     bf16_t* dkb = dqb + C;
     bf16_t* dvb = dqb + 2 * C;
 
@@ -368,6 +375,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
         if (snake_owner(rank) != wave) continue;
         const int qt = NT - 1 - rank;              // heaviest (most visible keys) first
         const int q0 = qt * 16;
+        if (q0 >= L) continue;                     // (short sequence of a packed batch)
         const int query = q0 + fr;
         const int nkt = causal ? qt + 1 : NT;
         const bf16x8 qf0 = lds_rowfrag(Qs, query, 0, fq), qf1 = lds_rowfrag(Qs, query, 1, fq);
@@ -507,18 +515,18 @@ static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, 
 }
 
 template <int NT>
-static int launch_fwd3(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
-                       hipStream_t s) {
+static int launch_fwd3(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu, int nseq, int L, int heads,
+                       int causal, hipStream_t s) {
     constexpr size_t lds = (size_t)3 * NT * 16 * AB_PITCH * 2;
-    hipLaunchKernelGGL(attn_fwd3_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, out, lse, nseq, L,
+    hipLaunchKernelGGL(attn_fwd3_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, out, lse, cu, nseq, L,
                        heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_fwd");
     return NEAT_OK;
 }
 
 template <int NT>
-static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq, int L,
-                      int heads, int causal, hipStream_t s) {
+static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, const int32_t* cu,
+                      int nseq, int L, int heads, int causal, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * NT * 16 * AB_PITCH * 2 + 2 * NT * 16 * 4 + (size_t)AB_WAVES * 16 * AB_PITCH * 2;
     static bool attr = false;
     if (!attr) {
@@ -527,8 +535,8 @@ static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* ls
         if (rc) return rc;
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, dout, lse, dqkv, nseq, L,
-                       heads, causal);
+    hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, dout, lse, dqkv, cu, nseq,
+                       L, heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_bwd");
     return NEAT_OK;
 }
@@ -537,30 +545,31 @@ static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* ls
 
 using namespace neat;
 
-extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
-                             void* stream) {
+extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens, int nseq, int L,
+                             int heads, int causal, void* stream) {
     NEAT_REQUIRE(qkv && out, NEAT_ERR_ARG, "neat_attn_fwd: null pointer");
     NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_fwd: bad shape");
+    NEAT_REQUIRE(!cu_seqlens || L <= 80, NEAT_ERR_SHAPE, "neat_attn_fwd: packed batches need L <= 80 (got %d)", L);
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
-        case 1: return launch_fwd3<1>(qkv, out, lse, nseq, L, heads, causal, s);
-        case 4: return launch_fwd3<4>(qkv, out, lse, nseq, L, heads, causal, s);
-        case 5: return launch_fwd3<5>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 1: return launch_fwd3<1>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
+        case 4: return launch_fwd3<4>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
+        case 5: return launch_fwd3<5>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 13: return launch_fwd<13>(qkv, out, lse, nseq, L, heads, causal, s);
         case 17: return launch_fwd<17>(qkv, out, lse, nseq, L, heads, causal, s);
         default: return set_error(NEAT_ERR_SHAPE, "neat_attn_fwd: sequence length %d > 272 unsupported", L);
     }
 }
 
-extern "C" int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, int nseq,
-                             int L, int heads, int causal, void* stream) {
+extern "C" int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv,
+                             const int32_t* cu_seqlens, int nseq, int L, int heads, int causal, void* stream) {
     NEAT_REQUIRE(qkv && dout && lse && dqkv, NEAT_ERR_ARG, "neat_attn_bwd: null pointer");
     NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
-        case 1: return launch_bwd<1>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
-        case 4: return launch_bwd<4>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
-        case 5: return launch_bwd<5>(qkv, dout, lse, dqkv, nseq, L, heads, causal, s);
+        case 1: return launch_bwd<1>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
+        case 4: return launch_bwd<4>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
+        case 5: return launch_bwd<5>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
         default: return set_error(NEAT_ERR_SHAPE, "neat_attn_bwd: sequence length %d > 80 unsupported", L);
     }
 }

@@ -32,6 +32,49 @@ __global__ void eot_index_kernel(const int64_t* __restrict__ tokens, int32_t* __
     eot[s] = bi;
 }
 
+// ---- packed ("varlen") text batches -------------------------------------------------------------------
+// With a causal mask and EOT pooling (open_clip/transformer.py:555-558, 655-661) no position after the EOT token
+// can influence the pooled feature or receive a gradient from it, so those rows are dead work.  The packed
+// layout keeps rows 0..eot of every sequence back to back: cu[s] = first row of sequence s, cu[nseq] = rows.
+__global__ __launch_bounds__(256) void pack_plan_kernel(const int64_t* __restrict__ tokens, int32_t* __restrict__ eot,
+                                                        int32_t* __restrict__ cu, int nseq, int L) {
+    extern __shared__ int32_t len_s[];
+    for (int s = threadIdx.x; s < nseq; s += blockDim.x) {
+        const int64_t* t = tokens + (long)s * L;
+        int64_t best = t[0];
+        int bi = 0;
+        for (int l = 1; l < L; ++l)
+            if (t[l] > best) { best = t[l]; bi = l; }
+        eot[s] = bi;
+        len_s[s] = bi + 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int s = 0; s < nseq; ++s) { cu[s] = acc; acc += len_s[s]; }
+        cu[nseq] = acc;
+    }
+}
+
+// one block per sequence: rows cu[s] .. cu[s+1]-1 <- token embedding + positional embedding
+__global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __restrict__ tokens,
+                                                           const int32_t* __restrict__ cu,
+                                                           const float* __restrict__ tok_emb,
+                                                           const float* __restrict__ pos_emb, float* __restrict__ x, int L,
+                                                           int C, int vocab) {
+    const int s = blockIdx.x;
+    const int r0 = cu[s], len = cu[s + 1] - r0;
+    const int c4 = C >> 2;
+    for (int i = threadIdx.x; i < len * c4; i += blockDim.x) {
+        const int pos = i / c4, c = i - pos * c4;
+        long id = tokens[(long)s * L + pos];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float4 a = reinterpret_cast<const float4*>(tok_emb + id * C)[c];
+        const float4 p = reinterpret_cast<const float4*>(pos_emb + (long)pos * C)[c];
+        reinterpret_cast<float4*>(x + (long)(r0 + pos) * C)[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
 // ---- pooled head forward: one block per sequence ----
 // pooled row -> LayerNorm (fp32) -> @ proj [C,D] -> optional F.normalize
 // (reference open_clip/model.py:278-286, open_clip/transformer.py:538-542, model.py:267)
@@ -257,12 +300,31 @@ extern "C" int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int
     return NEAT_OK;
 }
 
+extern "C" int neat_pack_plan(const int64_t* tokens, int32_t* eot, int32_t* cu_seqlens, int nseq, int L, void* stream) {
+    NEAT_REQUIRE(tokens && eot && cu_seqlens, NEAT_ERR_ARG, "neat_pack_plan: null pointer");
+    NEAT_REQUIRE(nseq > 0 && nseq <= 12000 && L > 0, NEAT_ERR_SHAPE, "neat_pack_plan: nseq=%d L=%d (nseq <= 12000)", nseq, L);
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), (size_t)nseq * 4, (hipStream_t)stream, tokens, eot,
+                       cu_seqlens, nseq, L);
+    NEAT_LAUNCH_CHECK("neat_pack_plan");
+    return NEAT_OK;
+}
+
+extern "C" int neat_embed_packed_fwd(const int64_t* tokens, const int32_t* cu_seqlens, const float* tok_emb,
+                                     const float* pos_emb, float* x, int nseq, int L, int C, int vocab, void* stream) {
+    NEAT_REQUIRE(tokens && cu_seqlens && tok_emb && pos_emb && x, NEAT_ERR_ARG, "neat_embed_packed_fwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && C % 4 == 0 && vocab > 0, NEAT_ERR_SHAPE, "neat_embed_packed_fwd: bad shape");
+    hipLaunchKernelGGL(embed_packed_kernel, dim3(nseq), dim3(256), 0, (hipStream_t)stream, tokens, cu_seqlens, tok_emb,
+                       pos_emb, x, L, C, vocab);
+    NEAT_LAUNCH_CHECK("neat_embed_packed_fwd");
+    return NEAT_OK;
+}
+
 extern "C" int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,
                                   const float* proj, float* feat, float* xe, float* mean, float* rstd, float* nrm,
                                   int nseq, int L, int C, int D, int normalize, float eps, void* stream) {
     NEAT_REQUIRE(x && gamma && beta && proj && feat, NEAT_ERR_ARG, "neat_pool_proj_fwd: null pointer");
-    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000, NEAT_ERR_SHAPE,
-                 "neat_pool_proj_fwd: bad shape C=%d D=%d", C, D);
+    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000,
+                 NEAT_ERR_SHAPE, "neat_pool_proj_fwd: bad shape C=%d D=%d", C, D);
     hipLaunchKernelGGL(pool_proj_fwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
                        x, row_idx, gamma, beta, proj, feat, xe, mean, rstd, nrm, L, C, D, normalize, eps);
     NEAT_LAUNCH_CHECK("neat_pool_proj_fwd");
@@ -276,8 +338,8 @@ extern "C" int neat_pool_proj_bwd(const float* dfeat, const float* feat, const f
     NEAT_REQUIRE(dfeat && xe && mean && rstd && gamma && proj && (dx_f32 || dx_bf16), NEAT_ERR_ARG,
                  "neat_pool_proj_bwd: null pointer");
     NEAT_REQUIRE(!normalize || (feat && nrm), NEAT_ERR_ARG, "neat_pool_proj_bwd: normalize needs feat, nrm");
-    NEAT_REQUIRE(nseq > 0 && L > 0 && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000, NEAT_ERR_SHAPE,
-                 "neat_pool_proj_bwd: bad shape");
+    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000,
+                 NEAT_ERR_SHAPE, "neat_pool_proj_bwd: bad shape");
     hipLaunchKernelGGL(pool_proj_bwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
                        dfeat, feat, nrm, xe, mean, rstd, gamma, proj, row_idx, dx_f32, dx_bf16, L, C, D, normalize);
     NEAT_LAUNCH_CHECK("neat_pool_proj_bwd");

@@ -47,13 +47,14 @@ class Stack:
         self.blocks = [BlockWeights(b, need_bwd) for b in transformer.resblocks]
         self.heads, self.causal = heads, causal
 
-    def forward(self, x, nseq: int, L: int, save: Optional[list]):
-        """x fp32 [nseq*L, C] -> fp32 [nseq*L, C].  With ``save`` a list, per-layer tensors needed by
-        ``backward`` are appended (and x buffers are never overwritten)."""
+    def forward(self, x, nseq: int, L: int, save: Optional[list], cu=None):
+        """x fp32 [rows, C] -> fp32 [rows, C] (rows = nseq*L, or cu[nseq] for a packed batch with L = longest
+        sequence).  With ``save`` a list, per-layer tensors needed by ``backward`` are appended (and x buffers
+        are never overwritten)."""
         for w in self.blocks:
             y, _, mu1, rs1 = ops.ln_fwd(x, w.ln1_w, w.ln1_b, save_stats=save is not None)
             qkv, _ = ops.gemm(y, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
-            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None)
+            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None, cu=cu)
             x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
             y, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=save is not None)
             h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"])
@@ -64,17 +65,18 @@ class Stack:
         return x
 
     def backward(self, dxf, dxb, nseq: int, L: int, saved: list, grads: List[Dict[str, torch.Tensor]],
-                 accumulate: bool):
-        """dxf fp32 / dxb bf16 [nseq*L, C]: gradient w.r.t. the stack output for the FIRST nseq sequences of
-        the saved forward.  grads[i] = dict(ln1_w, ln1_b, ln2_w, ln2_b) receive d(gamma), d(beta)."""
-        M = nseq * L
+                 accumulate: bool, cu=None):
+        """dxf fp32 / dxb bf16 [M, C]: gradient w.r.t. the stack output for the FIRST nseq sequences of the saved
+        forward (M = nseq*L rows, or cu[nseq] rows of a packed batch).  grads[i] = dict(ln1_w, ln1_b, ln2_w,
+        ln2_b) receive d(gamma), d(beta)."""
+        M = dxf.shape[0]
         for w, s, g in zip(reversed(self.blocks), reversed(saved), reversed(grads)):
             dh, _ = ops.gemm(dxb, w.wT["proj"], lib.EPI_GELU_BWD, aux=s["h"])
             dy2, _ = ops.gemm(dh, w.wT["fc"], lib.EPI_BF16)
             dxf, dxb = ops.ln_bwd(dy2, s["x1"][:M], w.ln2_w, s["mu2"], s["rs2"], dres=dxf, dgamma=g["ln2_w"],
                                   dbeta=g["ln2_b"], accumulate=accumulate, inplace_res=True)
             do, _ = ops.gemm(dxb, w.wT["o"], lib.EPI_BF16)
-            dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal)
+            dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal, cu=cu)
             dy1, _ = ops.gemm(dqkv, w.wT["qkv"], lib.EPI_BF16)
             dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, dgamma=g["ln1_w"],
                                   dbeta=g["ln1_b"], accumulate=accumulate, inplace_res=True)
@@ -95,26 +97,42 @@ class TextTower:
         self.lnf_w, self.lnf_b = model.ln_final.weight.detach(), model.ln_final.bias.detach()
         self.proj = model.text_projection.detach().contiguous()
 
-    def forward(self, tokens, normalize: bool, save: bool):
-        """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx)"""
+    def forward(self, tokens, normalize: bool, save: bool, packed: bool = False):
+        """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx).
+
+        ``packed``: run only positions 0..EOT of every sequence (rows back to back).  With the causal mask and
+        EOT pooling the positions after EOT cannot reach the pooled feature, nor receive gradient from it, so
+        features, losses and LN gradients are those of the full-length run (up to fp32 summation order)."""
         tokens = tokens.contiguous()
         nseq, L = tokens.shape
-        x = ops.embed_fwd(tokens, self.tok, self.pos)
         saved = [] if save else None
+        if packed:
+            eot, cu = ops.pack_plan(tokens)
+            cu_host = cu.cpu()                                    # one small D2H copy: row counts size the buffers
+            rows, Lmax = int(cu_host[-1]), int((cu_host[1:] - cu_host[:-1]).max())
+            x = ops.embed_packed_fwd(tokens, cu, rows, self.tok, self.pos)
+            x = self.stack.forward(x, nseq, Lmax, saved, cu=cu)
+            last = (cu[1:] - 1).contiguous()                      # absolute row of each EOT token
+            feat, head = ops.pool_proj_fwd(x, last, self.lnf_w, self.lnf_b, self.proj, nseq, 0, normalize, save=save)
+            ctx = dict(saved=saved, eot=last, head=head, feat=feat, nseq=nseq, L=Lmax, normalize=normalize, cu=cu,
+                       cu_host=cu_host) if save else None
+            return feat, ctx
+        x = ops.embed_fwd(tokens, self.tok, self.pos)
         x = self.stack.forward(x, nseq, L, saved)
         eot = ops.eot_index(tokens)
         feat, head = ops.pool_proj_fwd(x, eot, self.lnf_w, self.lnf_b, self.proj, nseq, L, normalize, save=save)
-        ctx = dict(saved=saved, eot=eot, head=head, feat=feat, nseq=nseq, L=L, normalize=normalize) if save else None
+        ctx = dict(saved=saved, eot=eot, head=head, feat=feat, nseq=nseq, L=L, normalize=normalize, cu=None) if save else None
         return feat, ctx
 
     def backward(self, ctx, dfeat, grads, accumulate: bool):
         """dfeat fp32 [n_grad, D] for the first n_grad sequences of the forward."""
-        n, L = dfeat.shape[0], ctx["L"]
-        dxf = torch.zeros(n * L, self.C, dtype=f32, device=dfeat.device)
-        dxb = torch.zeros(n * L, self.C, dtype=bf16, device=dfeat.device)
-        ops.pool_proj_bwd(dfeat.contiguous(), ctx["feat"], ctx["head"], self.lnf_w, self.proj, ctx["eot"], n, L,
-                          ctx["normalize"], dxf, dxb)
-        self.stack.backward(dxf, dxb, n, L, ctx["saved"], grads, accumulate)
+        n, L, cu = dfeat.shape[0], ctx["L"], ctx["cu"]
+        rows = n * L if cu is None else int(ctx["cu_host"][n])
+        dxf = torch.zeros(rows, self.C, dtype=f32, device=dfeat.device)
+        dxb = torch.zeros(rows, self.C, dtype=bf16, device=dfeat.device)
+        ops.pool_proj_bwd(dfeat.contiguous(), ctx["feat"], ctx["head"], self.lnf_w, self.proj, ctx["eot"], n,
+                          L if cu is None else 0, ctx["normalize"], dxf, dxb)
+        self.stack.backward(dxf, dxb, n, L, ctx["saved"], grads, accumulate, cu=cu)
 
 
 class VisionTower:

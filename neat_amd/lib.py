@@ -24,8 +24,10 @@ SIGNATURES = {
     "neat_ln_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _I, _P]),
     "neat_pack_weight_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_gemm_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "neat_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "neat_attn_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "neat_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "neat_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "neat_pack_plan": (_I, [_P, _P, _P, _I, _I, _P]),
+    "neat_embed_packed_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_eot_index": (_I, [_P, _P, _I, _I, _P]),
     "neat_pool_proj_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

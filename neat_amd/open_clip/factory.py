@@ -65,6 +65,8 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
             load_checkpoint(model, pretrained)
         else:
             raise RuntimeError(f"Pretrained weights ({pretrained}) not found locally; named tags need network access")
+    if "pack_tokens" in model_kwargs:
+        model.pack_tokens = bool(model_kwargs["pack_tokens"])
     model.to(device=torch.device(device))
     return model
 

@@ -10,6 +10,8 @@ missing library raises.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 from typing import Optional
@@ -97,7 +99,7 @@ class _EncodeText(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, tokens, normalize, save, *ln_params):
         tower = model._text_tower()
-        feat, tctx = tower.forward(tokens, normalize, save)
+        feat, tctx = tower.forward(tokens, normalize, save, packed=bool(getattr(model, "pack_tokens", False)))
         ctx.tower, ctx.tctx, ctx.model = tower, tctx, model
         return feat
 
@@ -136,6 +138,8 @@ class CLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
         self.logit_bias = None
         self._towers = {}
+        # opt-in: encode only positions 0..EOT of each caption (engine.TextTower.forward, packed=True)
+        self.pack_tokens = os.environ.get("NEAT_PACK_TOKENS", "0") not in ("", "0")
         self.init_parameters()
 
     # -- init: same distributions as the reference's text tower (open_clip/transformer.py:628-649) --

@@ -156,23 +156,27 @@ def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None,
 
 
 # ---- attention ----
-def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True):
+def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None):
+    """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0]."""
     C = heads * 64
-    if tuple(qkv.shape) != (nseq * L, 3 * C):
-        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(nseq * L, 3 * C)}")
-    out = torch.empty(nseq * L, C, dtype=bf16, device=qkv.device)
+    rows = qkv.shape[0]
+    if qkv.shape[1] != 3 * C or (cu is None and rows != nseq * L):
+        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} does not match nseq={nseq}, L={L}, C={C}")
+    out = torch.empty(rows, C, dtype=bf16, device=qkv.device)
     lse = torch.empty(nseq, heads, L, dtype=f32, device=qkv.device) if save_lse else None
-    lib.call("neat_attn_fwd", _p(qkv, bf16, "qkv"), _p(out), _p(lse), nseq, L, heads, int(causal), _stream())
+    lib.call("neat_attn_fwd", _p(qkv, bf16, "qkv"), _p(out), _p(lse), _p(cu, i32, "cu"), nseq, L, heads, int(causal),
+             _stream())
     return out, lse
 
 
-def attn_bwd(qkv, dout, lse, nseq, L, heads, causal):
+def attn_bwd(qkv, dout, lse, nseq, L, heads, causal, cu=None):
     C = heads * 64
-    if qkv.shape[0] < nseq * L or qkv.shape[1] != 3 * C or tuple(dout.shape) != (nseq * L, C):
+    rows = dout.shape[0]
+    if qkv.shape[0] < rows or qkv.shape[1] != 3 * C or dout.shape[1] != C or (cu is None and rows != nseq * L):
         raise RuntimeError("attn_bwd: shape mismatch")
-    dqkv = torch.empty(nseq * L, 3 * C, dtype=bf16, device=qkv.device)
-    lib.call("neat_attn_bwd", _p(qkv, bf16, "qkv"), _p(dout, bf16, "dout"), _p(lse, f32, "lse"), _p(dqkv), nseq, L,
-             heads, int(causal), _stream())
+    dqkv = torch.empty(rows, 3 * C, dtype=bf16, device=qkv.device)
+    lib.call("neat_attn_bwd", _p(qkv, bf16, "qkv"), _p(dout, bf16, "dout"), _p(lse, f32, "lse"), _p(dqkv),
+             _p(cu, i32, "cu"), nseq, L, heads, int(causal), _stream())
     return dqkv
 
 
@@ -188,6 +192,26 @@ def embed_fwd(tokens, tok_emb, pos_emb):
     return x
 
 
+def pack_plan(tokens):
+    """tokens int64 [nseq, L] -> (eot int32 [nseq], cu_seqlens int32 [nseq+1]) for the packed layout."""
+    nseq, L = tokens.shape
+    eot = torch.empty(nseq, dtype=i32, device=tokens.device)
+    cu = torch.empty(nseq + 1, dtype=i32, device=tokens.device)
+    lib.call("neat_pack_plan", _p(tokens, i64, "tokens"), _p(eot), _p(cu), nseq, L, _stream())
+    return eot, cu
+
+
+def embed_packed_fwd(tokens, cu, rows, tok_emb, pos_emb):
+    nseq, L = tokens.shape
+    vocab, C = tok_emb.shape
+    if pos_emb.shape[0] < L or pos_emb.shape[1] != C:
+        raise RuntimeError("embed_packed_fwd: positional embedding too short")
+    x = torch.empty(rows, C, dtype=f32, device=tokens.device)
+    lib.call("neat_embed_packed_fwd", _p(tokens, i64, "tokens"), _p(cu, i32, "cu"), _p(tok_emb, f32, "tok_emb"),
+             _p(pos_emb, f32, "pos_emb"), _p(x), nseq, L, C, vocab, _stream())
+    return x
+
+
 def eot_index(tokens):
     nseq, L = tokens.shape
     eot = torch.empty(nseq, dtype=i32, device=tokens.device)
@@ -197,7 +221,7 @@ def eot_index(tokens):
 
 def pool_proj_fwd(x, row_idx, gamma, beta, proj, nseq, L, normalize, save=True, eps=1e-5):
     C, D = proj.shape
-    if x.shape[0] < nseq * L or x.shape[1] != C:
+    if x.shape[0] < nseq * L or x.shape[1] != C or (L == 0 and row_idx is None):
         raise RuntimeError("pool_proj_fwd: shape mismatch")
     dev = x.device
     feat = torch.empty(nseq, D, dtype=f32, device=dev)

@@ -10,6 +10,8 @@ What differs from the reference, by design:
   * loss, gradient and the coarse alignment are fused fp32 kernels; AdamW is one launch when the optimizer
     is ``neat_amd.optim.AdamW`` (any torch optimizer over the same parameters also works);
   * the gallery buffer is sized from the model's embed dim (the reference hard-codes 512, :119);
+  * opt-in ``model.pack_tokens = True``: the text tower runs only positions 0..EOT of every caption (dead rows
+    behind the causal mask are dropped; same features, losses and LN gradients up to fp32 summation order);
   * data parallelism: every rank iterates the same batches, owns a contiguous row shard of
     each, all-gathers text features + coarse image features, and all-reduces the LN gradients.
 """
@@ -76,7 +78,8 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0):
     text, pos, neg, inv = tokens4
     Bl = text.shape[0]
     tower = model._text_tower()
-    feats, ctx = tower.forward(torch.cat([text, pos, inv, neg], dim=0), True, True)
+    feats, ctx = tower.forward(torch.cat([text, pos, inv, neg], dim=0), True, True,
+                               packed=bool(getattr(model, "pack_tokens", False)))
     t, p, v, n = feats[:Bl], feats[Bl:2 * Bl], feats[2 * Bl:3 * Bl], feats[3 * Bl:]
     coarse, idx, S = ops.coarse_align(t, p, n, gallery)
     if world > 1:

@@ -333,6 +333,34 @@ def test_data_parallel_step_equals_single_gpu(tmp_path):
     torch.testing.assert_close(r0["S"], S.cpu(), rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("name,B", [("neat-tiny", 9), ("ViT-B-32", 6)])
+def test_packed_tokens_equal_full_length(name, B):
+    """model.pack_tokens drops the positions after EOT (dead behind the causal mask): features, losses, coarse
+    indices, scores and the adapted LN parameters must equal the full-length run up to fp32 summation order."""
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    toks = [x.to(DEV) for x in synth.synth_caption_sets(B, t["context_length"], t["vocab_size"], 31)]
+    G = torch.nn.functional.normalize(torch.randn(20, cfg["embed_dim"], generator=torch.Generator().manual_seed(2)), dim=-1).to(DEV)
+    out = []
+    for packed in (False, True):
+        model, _ = _model(name, 0)
+        model.pack_tokens = packed
+        oc.freeze_parameters(model, False)
+        params, _ = oc.collect_params(model, False)
+        opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+        with torch.no_grad():
+            f = model.encode_text(toks[0], normalize=True).cpu()
+        for _ in range(2):
+            losses, idx, S = T.tta_step(model, opt, toks, G, 0.03, 0.07)
+        out.append(dict(f=f, losses=losses.cpu(), idx=idx.cpu(), S=S.cpu(), p=_flat_ln(model)))
+    a, b = out
+    assert float((a["f"] - b["f"]).abs().max()) < 2e-6          # same kernels row by row
+    torch.testing.assert_close(a["losses"], b["losses"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(a["idx"], b["idx"])
+    assert float((a["S"] - b["S"]).abs().max()) < 1e-5
+    assert rel_l2(b["p"], a["p"]) < 1e-6
+
+
 class _ListLoader:
     def __init__(self, batches, n):
         self.batches, self.dataset = batches, list(range(n))
