@@ -105,18 +105,21 @@ int neat_embed_packed_fwd(const int64_t* tokens, const int32_t* cu_seqlens, cons
 
 /* ---- pooled head: ln_final/ln_post on the pooled row -> @ projection -> F.normalize
  *      open_clip/model.py:278-286 (text), open_clip/transformer.py:538-542 + model.py:267 (vision) ---- */
-/* x f32 [nseq*L, C]; row index per sequence (NULL -> row 0 = class token); proj f32 [C, D].
- * L == 0: row_idx holds ABSOLUTE rows of x (packed batches).
- * Outputs: feat f32 [nseq, D] (normalised iff normalize), and for backward: xe f32 [nseq,C] (pooled rows),
- * mean/rstd [nseq], nrm [nseq] (L2 norm before clamping).  Backward-only outputs may be NULL. */
+/* x f32 [nseq*L, C]; row index per sequence (NULL -> row 0 = class token); proj_t f32 [D, C] = the TRANSPOSE of
+ * the projection parameter (frozen: transposed once by the caller).  L == 0: row_idx holds ABSOLUTE rows of x
+ * (packed batches).  Outputs: feat f32 [nseq, D] (normalised iff normalize), and for backward: xe f32 [nseq,C]
+ * (pooled rows), mean/rstd [nseq], nrm [nseq] (L2 norm before clamping); backward-only outputs may be NULL.
+ * ws: neat_pool_proj_ws_floats(nseq, C, D) floats.  C % 16 == 0. */
+long neat_pool_proj_ws_floats(int nseq, int C, int D);
 int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,
-                       const float* proj, float* feat, float* xe, float* mean, float* rstd, float* nrm,
+                       const float* proj_t, float* feat, float* xe, float* mean, float* rstd, float* nrm, float* ws,
                        int nseq, int L, int C, int D, int normalize, float eps, void* stream);
-/* dfeat f32 [nseq, D] -> gradient rows scattered into dx_f32 / dx_bf16 [nseq*L, C] (must be zeroed by the
- * caller); ln_final itself is not adapted (open_clip/factory.py:405-407). */
+/* dfeat f32 [nseq, D] -> gradient rows scattered into dx_f32 / dx_bf16 [rows, C] (must be zeroed by the caller);
+ * proj f32 [C, D] (the parameter as stored); ln_final itself is not adapted (open_clip/factory.py:405-407).
+ * D % 16 == 0. */
 int neat_pool_proj_bwd(const float* dfeat, const float* feat, const float* nrm, const float* xe,
                        const float* mean, const float* rstd, const float* gamma, const float* proj,
-                       const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, int nseq, int L, int C,
+                       const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, float* ws, int nseq, int L, int C,
                        int D, int normalize, void* stream);
 
 /* ---- vision stem: conv1 (stride = kernel) as a GEMM, open_clip/transformer.py:362,503-513 ---- */

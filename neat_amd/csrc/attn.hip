@@ -490,6 +490,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
 
 static inline int attn_nt(int L) {
     if (L <= 16) return 1;
+    if (L <= 32) return 2;
+    if (L <= 48) return 3;
     if (L <= 64) return 4;
     if (L <= 80) return 5;
     if (L <= 208) return 13;
@@ -553,6 +555,8 @@ extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, con
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
         case 1: return launch_fwd3<1>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
+        case 2: return launch_fwd3<2>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
+        case 3: return launch_fwd3<3>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 4: return launch_fwd3<4>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 5: return launch_fwd3<5>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 13: return launch_fwd<13>(qkv, out, lse, nseq, L, heads, causal, s);
@@ -568,6 +572,8 @@ extern "C" int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const fl
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
         case 1: return launch_bwd<1>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
+        case 2: return launch_bwd<2>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
+        case 3: return launch_bwd<3>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
         case 4: return launch_bwd<4>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
         case 5: return launch_bwd<5>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);
         default: return set_error(NEAT_ERR_SHAPE, "neat_attn_bwd: sequence length %d > 80 unsupported", L);

@@ -72,6 +72,9 @@ int check_hip(hipError_t e, const char* what);
         if (_rc) return _rc;     \
     } while (0)
 
+// loss.hip: C[M,N] = A[M,K] . B[N,K]^T, exact fp32 FMA chains in k order; K % 16 == 0
+int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace neat

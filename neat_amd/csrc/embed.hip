@@ -75,112 +75,98 @@ __global__ __launch_bounds__(256) void embed_packed_kernel(const int64_t* __rest
     }
 }
 
-// ---- pooled head forward: one block per sequence ----
-// pooled row -> LayerNorm (fp32) -> @ proj [C,D] -> optional F.normalize
-// (reference open_clip/model.py:278-286, open_clip/transformer.py:538-542, model.py:267)
-constexpr int PP_THREADS = 256;
+// ---- pooled head: pooled row -> LayerNorm (fp32) -> @ proj [C,D] -> optional F.normalize
+// (reference open_clip/model.py:278-286, open_clip/transformer.py:538-542, model.py:267), forward and data
+// gradient.  Three launches each way: a wave-per-sequence gather + LayerNorm, the exact-fp32 tile GEMM of
+// loss.hip for the projection (a per-sequence mat-vec re-read the 1 MB projection once per sequence), and a
+// wave-per-sequence normalise.
+constexpr int PP_THREADS = 256;   // 4 sequences per block
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    return t;
-}
-
-__global__ __launch_bounds__(PP_THREADS) void pool_proj_fwd_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ proj, float* __restrict__ feat, float* __restrict__ xe,
-    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ nrm, int L, int C, int D, int normalize,
-    float eps) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* z = sm;            // [C]
-    float* f = sm + C;        // [D]
-    float* red = f + D;       // [8]
-    const int s = blockIdx.x;
+__global__ __launch_bounds__(PP_THREADS) void pool_ln_fwd_kernel(const float* __restrict__ x,
+                                                                 const int32_t* __restrict__ row_idx,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ z,
+                                                                 float* __restrict__ xe, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int nseq, int L, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (PP_THREADS / 64) + (threadIdx.x >> 6);
+    if (s >= nseq) return;
     const long row = (long)s * L + (row_idx ? row_idx[s] : 0);
     const float* xr = x + row * C;
     float a = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float v = xr[c];
-        z[c] = v;
-        if (xe) xe[(long)s * C + c] = v;
-        a += v;
-    }
-    const float mu = block_sum(a, red) / C;
+    for (int c = lane; c < C; c += 64) a += xr[c];
+    const float mu = wave_sum(a) / C;
     float q = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float d = z[c] - mu;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mu;
         q += d * d;
     }
-    const float rs = rsqrtf(block_sum(q, red) / C + eps);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) z[c] = (z[c] - mu) * rs * gamma[c] + beta[c];
-    __syncthreads();
-    float n2 = 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(z[c], proj[(long)c * D + d], acc);
-        f[d] = acc;
-        n2 += acc * acc;
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    for (int c = lane; c < C; c += 64) {
+        const float v = xr[c];
+        if (xe) xe[(long)s * C + c] = v;
+        z[(long)s * C + c] = (v - mu) * rs * gamma[c] + beta[c];
     }
-    const float nr = sqrtf(block_sum(n2, red));
-    const float inv = normalize ? 1.0f / fmaxf(nr, 1e-12f) : 1.0f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) feat[(long)s * D + d] = f[d] * inv;
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         if (mean) mean[s] = mu;
         if (rstd) rstd[s] = rs;
-        if (nrm) nrm[s] = nr;
     }
 }
 
-// backward: dfeat -> (normalize bwd) -> @ proj^T -> LN backward (data grad only) -> scatter to pooled row
-__global__ __launch_bounds__(PP_THREADS) void pool_proj_bwd_kernel(
-    const float* __restrict__ dfeat, const float* __restrict__ feat, const float* __restrict__ nrm,
-    const float* __restrict__ xe, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ proj, const int32_t* __restrict__ row_idx,
-    float* __restrict__ dxf, bf16_t* __restrict__ dxb, int L, int C, int D, int normalize) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* df = sm;           // [D]
-    float* g = sm + D;        // [C]
-    float* red = g + C;       // [8]
-    const int s = blockIdx.x;
-    float dot = 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        const float v = dfeat[(long)s * D + d];
-        df[d] = v;
-        if (normalize) dot += v * feat[(long)s * D + d];
-    }
+// in place: feat[s] /= max(||feat[s]||, 1e-12) (iff normalize); nrm[s] = ||feat[s]|| before the division
+__global__ __launch_bounds__(PP_THREADS) void l2norm_rows_kernel(float* __restrict__ feat, float* __restrict__ nrm, int nseq,
+                                                                 int D, int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (PP_THREADS / 64) + (threadIdx.x >> 6);
+    if (s >= nseq) return;
+    float* f = feat + (long)s * D;
+    float n2 = 0.f;
+    for (int d = lane; d < D; d += 64) n2 = fmaf(f[d], f[d], n2);
+    const float nr = sqrtf(wave_sum(n2));
     if (normalize) {
-        dot = block_sum(dot, red);
-        const float inv = 1.0f / fmaxf(nrm[s], 1e-12f);
-        for (int d = threadIdx.x; d < D; d += blockDim.x) df[d] = (df[d] - feat[(long)s * D + d] * dot) * inv;
+        const float inv = 1.0f / fmaxf(nr, 1e-12f);
+        for (int d = lane; d < D; d += 64) f[d] *= inv;
     }
-    __syncthreads();
+    if (lane == 0 && nrm) nrm[s] = nr;
+}
+
+// df = (dfeat - feat <dfeat, feat>) / max(nrm, 1e-12)
+__global__ __launch_bounds__(PP_THREADS) void l2norm_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat,
+                                                                const float* __restrict__ nrm, float* __restrict__ df, int n,
+                                                                int D) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (PP_THREADS / 64) + (threadIdx.x >> 6);
+    if (s >= n) return;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot = fmaf(dfeat[(long)s * D + d], feat[(long)s * D + d], dot);
+    dot = wave_sum(dot);
+    const float inv = 1.0f / fmaxf(nrm[s], 1e-12f);
+    for (int d = lane; d < D; d += 64) df[(long)s * D + d] = (dfeat[(long)s * D + d] - feat[(long)s * D + d] * dot) * inv;
+}
+
+// dz -> LayerNorm data gradient -> scattered to the pooled row (ln_final / ln_post are not adapted)
+__global__ __launch_bounds__(PP_THREADS) void pool_ln_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ xe,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const int32_t* __restrict__ row_idx, float* __restrict__ dxf,
+                                                                 bf16_t* __restrict__ dxb, int n, int L, int C) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * (PP_THREADS / 64) + (threadIdx.x >> 6);
+    if (s >= n) return;
     const float mu = mean[s], rs = rstd[s];
-    // dz = df @ proj^T; one wave per output column c, lanes stride d
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < C; c += nw) {
-        float acc = 0.f;
-        for (int d = lane; d < D; d += 64) acc = fmaf(df[d], proj[(long)c * D + d], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) g[c] = acc * gamma[c];
-    }
-    __syncthreads();
     float s1 = 0.f, s2 = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float xh = (xe[(long)s * C + c] - mu) * rs;
-        s1 += g[c];
-        s2 += g[c] * xh;
+    for (int c = lane; c < C; c += 64) {
+        const float g = dz[(long)s * C + c] * gamma[c];
+        s1 += g;
+        s2 += g * ((xe[(long)s * C + c] - mu) * rs);
     }
-    s1 = block_sum(s1, red) / C;
-    s2 = block_sum(s2, red) / C;
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
     const long row = (long)s * L + (row_idx ? row_idx[s] : 0);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = lane; c < C; c += 64) {
+        const float g = dz[(long)s * C + c] * gamma[c];
         const float xh = (xe[(long)s * C + c] - mu) * rs;
-        const float o = rs * (g[c] - s1 - xh * s2);
+        const float o = rs * (g - s1 - xh * s2);
         if (dxf) dxf[row * C + c] = o;
         if (dxb) dxb[row * C + c] = f2bf(o);
     }
@@ -232,6 +218,17 @@ __global__ __launch_bounds__(256) void vision_embed_kernel(const float* __restri
         const float rs = rsqrtf(wave_sum(q) / C + eps);
         for (int c = lane; c < C; c += 64) x[row * C + c] = (src[c] + pr[c] - mu) * rs * gamma[c] + beta[c];
     }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
 }
 
 // VideoCLIP pooling (reference utils/video_utils/model.py:62-74,90-91): mean over frames, re-normalise
@@ -319,29 +316,48 @@ extern "C" int neat_embed_packed_fwd(const int64_t* tokens, const int32_t* cu_se
     return NEAT_OK;
 }
 
+extern "C" long neat_pool_proj_ws_floats(int nseq, int C, int D) { return (long)nseq * (C + D); }
+
 extern "C" int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const float* gamma, const float* beta,
-                                  const float* proj, float* feat, float* xe, float* mean, float* rstd, float* nrm,
-                                  int nseq, int L, int C, int D, int normalize, float eps, void* stream) {
-    NEAT_REQUIRE(x && gamma && beta && proj && feat, NEAT_ERR_ARG, "neat_pool_proj_fwd: null pointer");
-    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000,
-                 NEAT_ERR_SHAPE, "neat_pool_proj_fwd: bad shape C=%d D=%d", C, D);
-    hipLaunchKernelGGL(pool_proj_fwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
-                       x, row_idx, gamma, beta, proj, feat, xe, mean, rstd, nrm, L, C, D, normalize, eps);
+                                  const float* proj_t, float* feat, float* xe, float* mean, float* rstd, float* nrm,
+                                  float* ws, int nseq, int L, int C, int D, int normalize, float eps, void* stream) {
+    NEAT_REQUIRE(x && gamma && beta && proj_t && feat && ws, NEAT_ERR_ARG, "neat_pool_proj_fwd: null pointer");
+    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && C % 16 == 0, NEAT_ERR_SHAPE,
+                 "neat_pool_proj_fwd: bad shape C=%d D=%d (C %% 16 == 0)", C, D);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = cdiv(nseq, PP_THREADS / 64);
+    float* z = ws;
+    hipLaunchKernelGGL(pool_ln_fwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, x, row_idx, gamma, beta, z, xe, mean, rstd,
+                       nseq, L, C, eps);
+    int rc = launch_gemm_f32_nt(z, proj_t, feat, nseq, D, C, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(PP_THREADS), 0, s, feat, nrm, nseq, D, normalize);
     NEAT_LAUNCH_CHECK("neat_pool_proj_fwd");
     return NEAT_OK;
 }
 
 extern "C" int neat_pool_proj_bwd(const float* dfeat, const float* feat, const float* nrm, const float* xe,
                                   const float* mean, const float* rstd, const float* gamma, const float* proj,
-                                  const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, int nseq, int L, int C,
-                                  int D, int normalize, void* stream) {
-    NEAT_REQUIRE(dfeat && xe && mean && rstd && gamma && proj && (dx_f32 || dx_bf16), NEAT_ERR_ARG,
+                                  const int32_t* row_idx, float* dx_f32, uint16_t* dx_bf16, float* ws, int nseq, int L,
+                                  int C, int D, int normalize, void* stream) {
+    NEAT_REQUIRE(dfeat && xe && mean && rstd && gamma && proj && ws && (dx_f32 || dx_bf16), NEAT_ERR_ARG,
                  "neat_pool_proj_bwd: null pointer");
     NEAT_REQUIRE(!normalize || (feat && nrm), NEAT_ERR_ARG, "neat_pool_proj_bwd: normalize needs feat, nrm");
-    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && (C + D + 8) * 4 <= 60000,
-                 NEAT_ERR_SHAPE, "neat_pool_proj_bwd: bad shape");
-    hipLaunchKernelGGL(pool_proj_bwd_kernel, dim3(nseq), dim3(PP_THREADS), (size_t)(C + D + 8) * 4, (hipStream_t)stream,
-                       dfeat, feat, nrm, xe, mean, rstd, gamma, proj, row_idx, dx_f32, dx_bf16, L, C, D, normalize);
+    NEAT_REQUIRE(nseq > 0 && (L > 0 || (L == 0 && row_idx)) && C > 0 && D > 0 && D % 16 == 0, NEAT_ERR_SHAPE,
+                 "neat_pool_proj_bwd: bad shape (D %% 16 == 0)");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = cdiv(nseq, PP_THREADS / 64);
+    float* df = ws;
+    float* dz = ws + (long)nseq * D;
+    const float* dfp = dfeat;
+    if (normalize) {
+        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, dfeat, feat, nrm, df, nseq, D);
+        dfp = df;
+    }
+    int rc = launch_gemm_f32_nt(dfp, proj, dz, nseq, C, D, s);     // dz[n,C] = df[n,D] . proj[C,D]^T
+    if (rc) return rc;
+    hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, dz, xe, mean, rstd, gamma, row_idx, dx_f32,
+                       dx_bf16, nseq, L, C);
     NEAT_LAUNCH_CHECK("neat_pool_proj_bwd");
     return NEAT_OK;
 }

@@ -14,6 +14,9 @@ namespace neat {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / WAVE;
+// backward: 8 waves per block, so that half as many per-block partial rows reach the finalize pass
+constexpr int LNB_THREADS = 512;
+constexpr int LNB_WAVES = LNB_THREADS / WAVE;
 
 template <int NCH>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x,
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 }
 
 template <int NCH>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dxf,
     bf16_t* __restrict__ dxb, float* __restrict__ partial, int rows, int cols) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         if (c < nch) g[i] = reinterpret_cast<const float4*>(gamma)[c];
     }
     const float inv = 1.0f / (float)cols;
-    for (long row = (long)blockIdx.x * LN_WAVES + wave; row < rows; row += (long)gridDim.x * LN_WAVES) {
+    for (long row = (long)blockIdx.x * LNB_WAVES + wave; row < rows; row += (long)gridDim.x * LNB_WAVES) {
         const float mu = mean[row], rs = rstd[row];
         const float4* xr = reinterpret_cast<const float4*>(x + row * cols);
         const uint2* dyr = reinterpret_cast<const uint2*>(dy + row * cols);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         }
     }
     __syncthreads();
-    for (int stride = LN_WAVES / 2; stride > 0; stride >>= 1) {
+    for (int stride = LNB_WAVES / 2; stride > 0; stride >>= 1) {
         if (wave < stride) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         __syncthreads();
     }
     float* dst = partial + (long)blockIdx.x * 2 * cols;
-    for (int c = threadIdx.x; c < 2 * cols; c += LN_THREADS) dst[c] = red[c];
+    for (int c = threadIdx.x; c < 2 * cols; c += LNB_THREADS) dst[c] = red[c];
 }
 
 // 64 columns x 16 row-slices per block: coalesced 256-B reads, fixed summation order (deterministic)
@@ -225,10 +228,10 @@ extern "C" int neat_ln_fwd(const float* x, const float* gamma, const float* beta
 }
 
 extern "C" int neat_ln_bwd_blocks(int rows) {
-    // every block leaves one partial row pair behind; 4 blocks (16 waves) per CU keep the streaming part
-    // HBM-bound, and the finalize pass reads at most 1024 partial rows
-    int g = cdiv(rows, LN_WAVES * 8);
-    return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    // every block leaves one partial row pair behind; 2 blocks (16 waves) per CU keep the streaming part
+    // HBM-bound, and the finalize pass reads at most 512 partial rows
+    int g = cdiv(rows, LNB_WAVES * 8);
+    return g < 1 ? 1 : (g > 512 ? 512 : g);
 }
 
 extern "C" int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
@@ -239,8 +242,8 @@ extern "C" int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamm
                  "neat_ln_bwd: rows=%d cols=%d unsupported (cols %% 4 == 0, <= 1024)", rows, cols);
     hipStream_t s = (hipStream_t)stream;
     int nch = cdiv(cols / 4, 64);
-    dim3 grid(neat_ln_bwd_blocks(rows)), block(LN_THREADS);
-    size_t lds = partial ? (size_t)LN_WAVES * 2 * cols * sizeof(float) : 0;
+    dim3 grid(neat_ln_bwd_blocks(rows)), block(LNB_THREADS);
+    size_t lds = partial ? (size_t)LNB_WAVES * 2 * cols * sizeof(float) : 0;
     switch (nch) {
         case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, partial, rows, cols); break;
         case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dy, x, gamma, mean, rstd, dres, dx_f32, dx_bf16, partial, rows, cols); break;

@@ -285,17 +285,20 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
+    NEAT_REQUIRE(A && B && C, NEAT_ERR_ARG, "gemm_f32_nt: null pointer");
+    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % SG_K == 0, NEAT_ERR_SHAPE, "gemm_f32_nt: K=%d must be a multiple of 16", K);
+    hipLaunchKernelGGL(gemm_f32_nt_kernel, dim3(cdiv(N, SG_T), cdiv(M, SG_T)), dim3(256), 0, s, A, B, C, M, N, K);
+    NEAT_LAUNCH_CHECK("gemm_f32_nt");
+    return NEAT_OK;
+}
+
 }  // namespace neat
 
 using namespace neat;
 
 extern "C" int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
-    NEAT_REQUIRE(A && B && C, NEAT_ERR_ARG, "neat_gemm_f32_nt: null pointer");
-    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % SG_K == 0, NEAT_ERR_SHAPE, "neat_gemm_f32_nt: K=%d must be a multiple of 16", K);
-    hipLaunchKernelGGL(gemm_f32_nt_kernel, dim3(cdiv(N, SG_T), cdiv(M, SG_T)), dim3(256), 0, (hipStream_t)stream, A, B, C,
-                       M, N, K);
-    NEAT_LAUNCH_CHECK("neat_gemm_f32_nt");
-    return NEAT_OK;
+    return launch_gemm_f32_nt(A, B, C, M, N, K, (hipStream_t)stream);
 }
 
 extern "C" long neat_coarse_ws_floats(int B, int N) { return 2L * B * cdiv(N, SG_T); }

@@ -96,6 +96,7 @@ class TextTower:
         self.pos = model.positional_embedding.detach()
         self.lnf_w, self.lnf_b = model.ln_final.weight.detach(), model.ln_final.bias.detach()
         self.proj = model.text_projection.detach().contiguous()
+        self.proj_t = self.proj.t().contiguous()          # frozen: transposed once for the forward tile GEMM
 
     def forward(self, tokens, normalize: bool, save: bool, packed: bool = False):
         """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx).
@@ -113,14 +114,14 @@ class TextTower:
             x = ops.embed_packed_fwd(tokens, cu, rows, self.tok, self.pos)
             x = self.stack.forward(x, nseq, Lmax, saved, cu=cu)
             last = (cu[1:] - 1).contiguous()                      # absolute row of each EOT token
-            feat, head = ops.pool_proj_fwd(x, last, self.lnf_w, self.lnf_b, self.proj, nseq, 0, normalize, save=save)
+            feat, head = ops.pool_proj_fwd(x, last, self.lnf_w, self.lnf_b, self.proj_t, nseq, 0, normalize, save=save)
             ctx = dict(saved=saved, eot=last, head=head, feat=feat, nseq=nseq, L=Lmax, normalize=normalize, cu=cu,
                        cu_host=cu_host) if save else None
             return feat, ctx
         x = ops.embed_fwd(tokens, self.tok, self.pos)
         x = self.stack.forward(x, nseq, L, saved)
         eot = ops.eot_index(tokens)
-        feat, head = ops.pool_proj_fwd(x, eot, self.lnf_w, self.lnf_b, self.proj, nseq, L, normalize, save=save)
+        feat, head = ops.pool_proj_fwd(x, eot, self.lnf_w, self.lnf_b, self.proj_t, nseq, L, normalize, save=save)
         ctx = dict(saved=saved, eot=eot, head=head, feat=feat, nseq=nseq, L=L, normalize=normalize, cu=None) if save else None
         return feat, ctx
 
@@ -153,7 +154,7 @@ class VisionTower:
         self.pos = v.positional_embedding.detach()
         self.lnpre = (v.ln_pre.weight.detach(), v.ln_pre.bias.detach())
         self.lnpost = (v.ln_post.weight.detach(), v.ln_post.bias.detach())
-        self.proj = v.proj.detach().contiguous()
+        self.proj_t = v.proj.detach().t().contiguous()
         self.stack = Stack(v.transformer, self.C // 64, False, need_bwd=False)
 
     def forward(self, images, normalize: bool):
@@ -166,5 +167,5 @@ class VisionTower:
         pe, _ = ops.gemm(patches, self.w_patch, lib.EPI_F32)
         x = ops.vision_embed(pe, self.cls, self.pos, self.lnpre[0], self.lnpre[1], n, P)
         x = self.stack.forward(x, n, P + 1, None)
-        feat, _ = ops.pool_proj_fwd(x, None, self.lnpost[0], self.lnpost[1], self.proj, n, P + 1, normalize, save=False)
+        feat, _ = ops.pool_proj_fwd(x, None, self.lnpost[0], self.lnpost[1], self.proj_t, n, P + 1, normalize, save=False)
         return feat

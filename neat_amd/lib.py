@@ -30,8 +30,9 @@ SIGNATURES = {
     "neat_embed_packed_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_eot_index": (_I, [_P, _P, _I, _I, _P]),
-    "neat_pool_proj_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "neat_pool_proj_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "neat_pool_proj_ws_floats": (_L, [_I, _I, _I]),
+    "neat_pool_proj_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "neat_pool_proj_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "neat_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "neat_vision_embed": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "neat_frame_mean_norm": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -219,8 +219,9 @@ def eot_index(tokens):
     return eot
 
 
-def pool_proj_fwd(x, row_idx, gamma, beta, proj, nseq, L, normalize, save=True, eps=1e-5):
-    C, D = proj.shape
+def pool_proj_fwd(x, row_idx, gamma, beta, proj_t, nseq, L, normalize, save=True, eps=1e-5):
+    """proj_t: [D, C] = transpose of the projection parameter (frozen; transposed once by the caller)."""
+    D, C = proj_t.shape
     if x.shape[0] < nseq * L or x.shape[1] != C or (L == 0 and row_idx is None):
         raise RuntimeError("pool_proj_fwd: shape mismatch")
     dev = x.device
@@ -229,17 +230,19 @@ def pool_proj_fwd(x, row_idx, gamma, beta, proj, nseq, L, normalize, save=True, 
     mean = torch.empty(nseq, dtype=f32, device=dev) if save else None
     rstd = torch.empty(nseq, dtype=f32, device=dev) if save else None
     nrm = torch.empty(nseq, dtype=f32, device=dev) if save else None
-    lib.call("neat_pool_proj_fwd", _p(x, f32, "x"), _p(row_idx, i32), _p(gamma, f32), _p(beta, f32), _p(proj, f32),
-             _p(feat), _p(xe), _p(mean), _p(rstd), _p(nrm), nseq, L, C, D, int(normalize), eps, _stream())
+    ws = torch.empty(nseq * (C + D), dtype=f32, device=dev)
+    lib.call("neat_pool_proj_fwd", _p(x, f32, "x"), _p(row_idx, i32), _p(gamma, f32), _p(beta, f32), _p(proj_t, f32),
+             _p(feat), _p(xe), _p(mean), _p(rstd), _p(nrm), _p(ws), nseq, L, C, D, int(normalize), eps, _stream())
     return feat, (xe, mean, rstd, nrm)
 
 
 def pool_proj_bwd(dfeat, feat, saved, gamma, proj, row_idx, nseq, L, normalize, dxf, dxb):
     xe, mean, rstd, nrm = saved
     C, D = proj.shape
+    ws = torch.empty(nseq * (C + D), dtype=f32, device=dfeat.device)
     lib.call("neat_pool_proj_bwd", _p(dfeat, f32, "dfeat"), _p(feat, f32), _p(nrm, f32), _p(xe, f32), _p(mean, f32),
-             _p(rstd, f32), _p(gamma, f32), _p(proj, f32), _p(row_idx, i32), _p(dxf, f32), _p(dxb, bf16), nseq, L, C, D,
-             int(normalize), _stream())
+             _p(rstd, f32), _p(gamma, f32), _p(proj, f32), _p(row_idx, i32), _p(dxf, f32), _p(dxb, bf16), _p(ws), nseq, L,
+             C, D, int(normalize), _stream())
 
 
 # ---- vision stem ----

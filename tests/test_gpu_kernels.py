@@ -176,9 +176,29 @@ def _attn_case(nseq, L, heads, causal, seed, bwd=True):
 
 @pytest.mark.parametrize("nseq,L,heads,causal", [(3, 77, 8, True), (5, 77, 12, True), (2, 50, 12, False),
                                                   (4, 16, 2, True), (3, 5, 2, False), (2, 64, 1, True),
-                                                  (7, 80, 2, False), (1, 33, 3, True)])
+                                                  (7, 80, 2, False), (1, 33, 3, True), (4, 22, 8, True), (3, 32, 2, False),
+                                                  (2, 47, 4, True)])
 def test_attention_fwd_bwd(nseq, L, heads, causal):
     _attn_case(nseq, L, heads, causal, 10 + L)
+
+
+def test_attention_packed_batches():
+    """cu_seqlens: sequences of different lengths back to back; every sequence must equal its own dense run."""
+    heads, C = 4, 256
+    lens = [5, 22, 1, 16, 17, 33, 9]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    rows = int(cu[-1])
+    qkv = bf(torch.randn(rows, 3 * C, generator=g(7)) * 0.8)
+    do = bf(torch.randn(rows, C, generator=g(8)))
+    Lmax = max(lens)
+    o, lse = ops.attn_fwd(qkv.to(DEV), len(lens), Lmax, heads, True, cu=cu.to(DEV))
+    d = ops.attn_bwd(qkv.to(DEV), do.to(DEV), lse, len(lens), Lmax, heads, True, cu=cu.to(DEV))
+    for i, n in enumerate(lens):
+        a, b = int(cu[i]), int(cu[i + 1])
+        o_ref, p = O.attention_fwd(qkv[a:b].float().view(1, n, 3 * C), heads, True)
+        assert rel_l2(o[a:b].float().cpu(), o_ref.reshape(n, C)) < 8e-3
+        d_ref = O.attention_bwd(do[a:b].float().view(1, n, C), qkv[a:b].float().view(1, n, 3 * C), p, heads)
+        assert rel_l2(d[a:b].float().cpu(), d_ref.reshape(n, 3 * C)) < 1.5e-2
 
 
 @pytest.mark.parametrize("L,heads", [(197, 12), (257, 16), (100, 2)])
@@ -221,7 +241,8 @@ def test_pool_proj_fwd_bwd(normalize):
     z, mu, rs = O.layer_norm_fwd(xe, gam, bet)
     f = z @ proj
     ref, nrm = O.l2_normalize(f) if normalize else (f, None)
-    feat, saved = ops.pool_proj_fwd(x.to(DEV), idx.to(DEV), gam.to(DEV), bet.to(DEV), proj.to(DEV), n, L, normalize)
+    feat, saved = ops.pool_proj_fwd(x.to(DEV), idx.to(DEV), gam.to(DEV), bet.to(DEV), proj.t().contiguous().to(DEV), n, L,
+                                    normalize)
     assert rel_l2(feat.cpu(), ref) < 1e-5
     dfeat = torch.randn(n, D, generator=g(6))
     df = O.l2_normalize_bwd(dfeat, ref, nrm) if normalize else dfeat
