@@ -168,14 +168,21 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (j + 1 < J && (wave >> 2) == ((j + 1) & 1)) issue_piece(j + 1);
 
-        if (kh == 0) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         const int nt0 = (cb * CB >> 4) + wave * NI;                 // first of this wave's NI column tiles
         const int nvalid = (N >> 4) - nt0;                          // how many of them exist (<=0: idle)
+        if (kh == 0) {
+            // the accumulators start from the bias (lane: columns tile*16 + 4*fq .. +3 of every row tile), which
+            // takes the bias add out of the epilogue
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU) {
+                    if (i < nvalid) b0 = *reinterpret_cast<const f32x4*>(bias + (nt0 + i) * 16 + fq * 4);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[i][t] = b0;
+            }
+        }
         if (nvalid > 0) {
             const char* buf = lds + (j & 1) * P_BUF_BYTES;
             const uint4* wp = Wp + ((long)nt0 * ksK + (long)kh * ksteps) * 64 + lane;
@@ -206,10 +213,6 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                     const int cl = lane % CPW, rq = lane / CPW;
                     const int n = nt0 * 16 + cl * 4;
                     const bool col_ok = cl * 4 < ncols;
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                        if (col_ok) bv = *reinterpret_cast<const float4*>(bias + n);
-                    }
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                             const int m = rowm0 + t * 16 + row;
                             if (m >= M || !col_ok) continue;
                             const long o = (long)m * N + n;
-                            float v0 = a4.x + bv.x, v1 = a4.y + bv.y, v2 = a4.z + bv.z, v3 = a4.w + bv.w;
+                            const float v0 = a4.x, v1 = a4.y, v2 = a4.z, v3 = a4.w;
                             if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
                                 const float4 rr = *reinterpret_cast<const float4*>(res + o);
                                 *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
@@ -240,15 +243,6 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                     const int er = lane >> 2, eq = lane & 3;
                     const int n = nt0 * 16 + eq * 8;
                     const bool col_ok = eq * 8 < ncols;
-                    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_GELU) {
-                        if (col_ok) {
-                            const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
-                            const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
-                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-                            bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-                        }
-                    }
                     const char* rd0 = stg + er * 128 + (((2 * eq) ^ sw(er)) << 4);
                     const char* rd1 = stg + er * 128 + (((2 * eq + 1) ^ sw(er)) << 4);
                     char* wr = stg + fr * 128;
@@ -263,8 +257,7 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                         const int m = rowm0 + t * 16 + er;
                         if (m >= M || !col_ok) continue;
                         const long o = (long)m * N + n;
-                        float v[8] = {a0.x + bv[0], a0.y + bv[1], a0.z + bv[2], a0.w + bv[3],
-                                      a1.x + bv[4], a1.y + bv[5], a1.z + bv[6], a1.w + bv[7]};
+                        const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                         if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
                             *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
                                 pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
