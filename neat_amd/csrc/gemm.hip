@@ -33,6 +33,8 @@
 // Rows >= M are clamped on load and masked on store; N needs % 16, K needs % 128.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace neat {
@@ -203,89 +205,104 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                 // wave-instruction (32-B requests).  Each 16 x (NI*16) tile is therefore transposed through a
                 // wave-private LDS slab (XOR-swizzled 16-B chunks, conflict-free both ways) so that consecutive
                 // lanes cover one row and every lane moves 16 B per global access.
-                char* stg = lds + (j & 1) * P_BUF_BYTES + wave * (NI * 1024);
+                // two slabs per wave (even / odd chunk), so that the transposing write of chunk t+1 does not wait
+                // for the reads of chunk t
+                char* stg = lds + (j & 1) * P_BUF_BYTES + wave * (2 * NI * 1024);
+                constexpr int SLAB2 = NI * 1024;
                 constexpr int CPW = NI * 4;                             // 16-B fp32 chunks per row of the slab
                 const int ncols = nvalid < NI ? nvalid * 16 : NI * 16;  // valid columns of this wave's slab
                 const int rowm0 = sub << 7;
-                if constexpr (EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32) {
-                    // fp32 outputs: a lane owns 4 columns (16 B), 8 lanes cover a 128-B row segment
-                    constexpr int RPI = 64 / CPW;                       // rows per read instruction
-                    const int cl = lane % CPW, rq = lane / CPW;
-                    const int n = nt0 * 16 + cl * 4;
-                    const bool col_ok = cl * 4 < ncols;
+                // FULL = whole unit inside the matrix: straight-line code without per-chunk conditions, which lets
+                // the compiler run the LDS round trip of chunk t+1 under the arithmetic and stores of chunk t
+                auto epilogue = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    if constexpr (EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32) {
+                        // fp32 outputs: a lane owns 4 columns (16 B), 8 lanes cover a 128-B row segment
+                        constexpr int RPI = 64 / CPW;                   // rows per read instruction
+                        const int cl = lane % CPW, rq = lane / CPW;
+                        const int n = nt0 * 16 + cl * 4;
+                        const bool col_ok = cl * 4 < ncols;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                        for (int t = 0; t < 8; ++t) {
+                            char* sl = stg + (t & 1) * SLAB2;
 #pragma unroll
-                        for (int i = 0; i < NI; ++i)
-                            *reinterpret_cast<f32x4*>(stg + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
+                            for (int i = 0; i < NI; ++i)
+                                *reinterpret_cast<f32x4*>(sl + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
 #pragma unroll
-                        for (int r = 0; r < 16 / RPI; ++r) {
-                            const int row = r * RPI + rq;
-                            const float4 a4 = *reinterpret_cast<const float4*>(stg + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
-                            const int m = rowm0 + t * 16 + row;
-                            if (m >= M || !col_ok) continue;
+                            for (int r = 0; r < 16 / RPI; ++r) {
+                                const int row = r * RPI + rq;
+                                const float4 a4 = *reinterpret_cast<const float4*>(sl + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
+                                const int m = rowm0 + t * 16 + row;
+                                if constexpr (!FULL) {
+                                    if (m >= M || !col_ok) continue;
+                                }
+                                const long o = (long)m * N + n;
+                                if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                                    const float4 rr = *reinterpret_cast<const float4*>(res + o);
+                                    *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(a4.x + rr.x, a4.y + rr.y, a4.z + rr.z, a4.w + rr.w);
+                                } else {
+                                    *reinterpret_cast<float4*>((float*)out0 + o) = a4;
+                                }
+                            }
+                        }
+                    } else {
+                        // bf16 outputs: a lane owns 8 columns (16 B of bf16), 4 lanes cover the wave's 32 columns,
+                        // one wave-instruction covers the whole 16-row tile.  Slab swizzle sw(r) is conflict-free
+                        // for the ds_write_b128 lane groups (8 contiguous lanes) and the ds_read_b128 ones.
+                        static_assert(NI == 2, "bf16 epilogue assumes a 32-column slab");
+                        auto sw = [](int r) { return (r & 3) ^ ((r & 4) ? 5 : 0); };
+                        const int er = lane >> 2, eq = lane & 3;
+                        const int n = nt0 * 16 + eq * 8;
+                        const bool col_ok = eq * 8 < ncols;
+                        const char* rd0 = stg + er * 128 + (((2 * eq) ^ sw(er)) << 4);
+                        const char* rd1 = stg + er * 128 + (((2 * eq + 1) ^ sw(er)) << 4);
+                        char* wr = stg + fr * 128;
+                        const int wsw = sw(fr);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i)
+                                *reinterpret_cast<f32x4*>(wr + (t & 1) * SLAB2 + (((i * 4 + fq) ^ wsw) << 4)) = acc[i][t];
+                            const float4 a0 = *reinterpret_cast<const float4*>(rd0 + (t & 1) * SLAB2);
+                            const float4 a1 = *reinterpret_cast<const float4*>(rd1 + (t & 1) * SLAB2);
+                            const int m = rowm0 + t * 16 + er;
+                            if constexpr (!FULL) {
+                                if (m >= M || !col_ok) continue;
+                            }
                             const long o = (long)m * N + n;
-                            const float v0 = a4.x, v1 = a4.y, v2 = a4.z, v3 = a4.w;
-                            if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                                const float4 rr = *reinterpret_cast<const float4*>(res + o);
-                                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
-                            } else {
-                                *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(v0, v1, v2, v3);
+                            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                            if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
+                                *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
+                                    pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                            } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                                // the saved pre-activation is the bf16-rounded value; GELU is applied to the same
+                                // rounded value so that forward and backward see one h
+                                uint32_t hp[4], up[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                    up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
+                                }
+                                if (FULL || out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                                *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
+                            } else {  // NEAT_EPI_GELU_BWD
+                                const uint4 hq = *reinterpret_cast<const uint4*>(aux + o);
+                                const uint32_t hp[4] = {hq.x, hq.y, hq.z, hq.w};
+                                uint32_t dp[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                    dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
+                                }
+                                *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
                             }
                         }
                     }
-                } else {
-                    // bf16 outputs: a lane owns 8 columns (16 B of bf16), 4 lanes cover the wave's 32 columns,
-                    // one wave-instruction covers the whole 16-row tile.  Slab swizzle sw(r) is conflict-free for
-                    // the ds_write_b128 lane groups (8 contiguous lanes) and the ds_read_b128 ones.
-                    static_assert(NI == 2, "bf16 epilogue assumes a 32-column slab");
-                    auto sw = [](int r) { return (r & 3) ^ ((r & 4) ? 5 : 0); };
-                    const int er = lane >> 2, eq = lane & 3;
-                    const int n = nt0 * 16 + eq * 8;
-                    const bool col_ok = eq * 8 < ncols;
-                    const char* rd0 = stg + er * 128 + (((2 * eq) ^ sw(er)) << 4);
-                    const char* rd1 = stg + er * 128 + (((2 * eq + 1) ^ sw(er)) << 4);
-                    char* wr = stg + fr * 128;
-                    const int wsw = sw(fr);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i)
-                            *reinterpret_cast<f32x4*>(wr + (((i * 4 + fq) ^ wsw) << 4)) = acc[i][t];
-                        const float4 a0 = *reinterpret_cast<const float4*>(rd0);
-                        const float4 a1 = *reinterpret_cast<const float4*>(rd1);
-                        const int m = rowm0 + t * 16 + er;
-                        if (m >= M || !col_ok) continue;
-                        const long o = (long)m * N + n;
-                        const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                        if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
-                            *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
-                                pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-                        } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
-                            // the saved pre-activation is the bf16-rounded value; GELU is applied to the same
-                            // rounded value so that forward and backward see one h
-                            uint32_t hp[4], up[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
-                                const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
-                                up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
-                            }
-                            if (out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-                            *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
-                        } else {  // NEAT_EPI_GELU_BWD
-                            const uint4 hq = *reinterpret_cast<const uint4*>(aux + o);
-                            const uint32_t hp[4] = {hq.x, hq.y, hq.z, hq.w};
-                            uint32_t dp[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
-                                dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
-                            }
-                            *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
-                        }
-                    }
-                }
+                };
+                const bool full = rowm0 + 128 <= M && ncols == NI * 16 && (EPI != NEAT_EPI_BIAS_GELU || out0 != nullptr);
+                if (full) epilogue(std::true_type{});
+                else epilogue(std::false_type{});
             }
         }
     }
