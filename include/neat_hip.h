@@ -73,6 +73,18 @@ int neat_pack_weight_bf16(const float* src, uint16_t* dst, int N, int K, int tra
 int neat_gemm_bf16(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                    const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                    void* stream);
+/* The same GEMM in its second form ("tile256": 256 x 256 units, one workgroup per CU, both operands by LDS-DMA, see
+ * csrc/gemm.hip), for N % 256 == 0, K % 128 == 0, N <= 8192.  Its weights are packed into the kernel's LDS image:
+ * 16-KiB half-tiles ((cb*(K/64) + kt)*2 + h), each 128 rows x 8 chunks of 16 B; row lr holds column
+ * cb*256 + (lr>>5)*64 + h*32 + (lr&31), chunk p holds k = kt*64 + (p ^ swz(lr))*8 .. +7,
+ * swz(lr) = ((lr>>1)&7) ^ (((lr>>4)&1)<<1).  Same arguments, epilogues and results as neat_gemm_bf16 (bf16 operands,
+ * fp32 accumulation in k order per 32-k step).  neat_gemm_prefers_t256 returns 1 where this form is the faster one
+ * on MI355X (store-only epilogues on grids of >= 1.5 rounds of units); a caller keeps the layout(s) it will use. */
+int neat_pack_weight_bf16_t256(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream);
+int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
+                        const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
+                        void* stream);
+int neat_gemm_prefers_t256(int M, int N, int K, int epilogue);
 
 /* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
 /* qkv bf16 [rows, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [rows, C];

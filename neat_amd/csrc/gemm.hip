@@ -373,6 +373,404 @@ static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias,
     return launch_gemm_c<EPI, P_BKH, P_NI, 2>(A, Wp, bias, res, aux, out0, out1, M, N, K, grid, s);
 }
 
+
+// =====================================================================================================
+// tile256: the second GEMM structure, used whenever N % 256 == 0 and K % 128 == 0 (every linear of the
+// ViT-B/32, B/16 and L/14 towers).  It follows the 256 x 256 "8-phase" plan for gfx950:
+//
+//  * unit = 256 rows x 256 columns, ONE 512-thread workgroup per CU (<= 256 VGPRs), waves as 2 (M) x 4 (N):
+//    a wave owns 128 x 64 outputs = 8 x 4 accumulator tiles (128 VGPRs);
+//  * BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4): no wave ever waits for a weight load in
+//    its in-order vmcnt queue.  K advances in K-tiles of 64; a K-tile is four 16-KiB half-tiles
+//    (A0 A1 B0 B1, 128 rows x 64 k each), double buffered = 128 KiB.  The half-tiles are cut by
+//    CONSUMPTION order, not by position: A0 = row tiles 0..3 of both wave rows, A1 = row tiles 4..7,
+//    B0 / B1 = the first / second 32 columns of every wave column;
+//  * a K-tile is four phases (one accumulator quadrant, 16 MFMAs per wave, each): P0 reads B0+A0 (12
+//    ds_read_b128), P1 reads B1, P2 reads A1, P3 reads nothing (B0 is still in registers); every phase
+//    restages ONE half-tile that was read a phase (or two) earlier with the data of the K-tile after next,
+//    so three half-tiles are always in flight; the only vmcnt wait is vmcnt(6) in P3, once per K-tile;
+//  * two raw s_barriers per phase, and the two wave rows run ONE barrier apart (wr == 1 takes an extra barrier
+//    at the start, wr == 0 at the end): on every SIMD one wave issues its 16 MFMAs while its partner reads
+//    fragments and issues LDS-DMA;
+//  * the weights are packed once into exactly this LDS image (neat_pack_weight_bf16), so a weight half-tile is
+//    one contiguous 16-KiB read; the activation half-tile is read as 128-B row segments with the XOR swizzle
+//    applied to the source address;
+//  * epilogue straight from the accumulators, no LDS round trip: W is the MFMA A operand, so a lane holds 4
+//    consecutive columns of one row; for bf16 outputs the two column tiles of a pair are read from LDS in
+//    the interleaved order (8q+4i+j), which makes a lane's 8 values 8 CONSECUTIVE columns = one 16-B store,
+//    64 contiguous bytes per row and instruction.  fp32 outputs keep the natural order (16 B per lane);
+//  * the bias lives in LDS (fp32 copy made once per workgroup) so that no ordinary VGPR load sits in the
+//    vmcnt queue between LDS-DMA operations.
+//
+// LDS image of a half-tile: row lr (0..127) x 8 chunks of 16 B; chunk c of row lr is stored at chunk
+// c ^ swz(lr), swz(lr) = ((lr >> 1) & 7) ^ (((lr >> 4) & 1) << 1): conflict-free for the lane groups of
+// ds_read_b128 with both the natural and the interleaved row order.
+constexpr int T_THREADS = 512;
+constexpr int T_HALF = 16384;                 // bytes of a half-tile
+constexpr int T_BUF = 4 * T_HALF;             // one K-tile: A0 A1 B0 B1
+constexpr int T_BIAS = 2 * T_BUF;             // fp32 bias copy behind the two K-tile buffers
+constexpr int T_MAXN = 8192;
+constexpr int T_LDS = T_BIAS + T_MAXN * 4;    // 160 KiB
+constexpr int T_A0 = 0, T_B0 = 2;                // half-tile slots of a K-tile buffer: A0 A1 B0 B1
+
+__host__ __device__ __forceinline__ int t_swz(int lr) { return ((lr >> 1) & 7) ^ (((lr >> 4) & 1) << 1); }
+
+__host__ __device__ constexpr bool t256_shape_ok(int N, int K) { return N % 256 == 0 && K % 128 == 0 && N <= T_MAXN; }
+
+#define T_BARRIER()                                  \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        asm volatile("s_barrier" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
+    const bf16_t* __restrict__ A, const char* __restrict__ Wp, const float* __restrict__ bias, const float* res,
+    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool PERM = !(EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32);   // bf16 outputs
+    constexpr bool HAS_BIAS = EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // unit -> workgroup deal, XCD-aware exactly like gemm_panel_kernel: all column blocks of a 256-row block
+    // run on workgroups of one XCD at about the same time, so the block is fetched into that L2 once
+    const int nrb = (M + 255) >> 8;
+    const int ncb = N >> 8;
+    const int G_ = gridDim.x;
+    const int X = (G_ & 7) == 0 ? 8 : 1;
+    const int xcd = blockIdx.x % X, wg = blockIdx.x / X, WX = G_ / X;
+    const int nrx = (nrb - xcd + X - 1) / X;
+    const int U = (nrx * ncb - wg + WX - 1) / WX;                 // units of this workgroup
+    if (U <= 0) return;                                           // uniform, before any barrier
+    const int nkt = K >> 6;                                       // K-tiles per unit (even: K % 128 == 0)
+    const long wcb_bytes = (long)nkt * 2 * T_HALF;                // packed bytes of one column block
+    auto unit_of = [&](int t, int& row0, const char*& wb) {
+        const int v = wg + t * WX;
+        const int i = v / ncb;
+        const int cb = v - i * ncb;
+        row0 = (xcd + X * i) << 8;
+        wb = Wp + cb * wcb_bytes;
+    };
+
+    if constexpr (HAS_BIAS) {
+        for (int i = threadIdx.x * 4; i < N; i += T_THREADS * 4)
+            *reinterpret_cast<float4*>(lds + T_BIAS + i * 4) = *reinterpret_cast<const float4*>(bias + i);
+    }
+
+    // ---- staging (LDS-DMA): every wave issues 2 of the 16 wave-instructions of a half-tile ----
+    // instruction q of this wave covers half-tile rows lr = (2*wave+q)*8 + (lane>>3), LDS chunk lane&7
+    int st_urow[2], st_cb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int lr = (2 * wave + q) * 8 + (lane >> 3);
+        st_urow[q] = (lr >> 6) * 128 + (lr & 63);                 // unit row of A0's row lr (A1: + 64)
+        st_cb[q] = ((lane & 7) ^ t_swz(lr)) * 16;                 // source byte offset inside the 128-B k segment
+    }
+    const uint32_t st_lds = lds_base + wave * 2048;
+    auto stage_a = [&](int h, int pb, int row0, int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int gr = row0 + st_urow[q] + h * 64;
+            gr = gr < M ? gr : M - 1;
+            const char* src = reinterpret_cast<const char*>(A) + ((long)gr * K + kt * 64) * 2 + st_cb[q];
+            glds16(src, st_lds + pb * T_BUF + (T_A0 + h) * T_HALF + q * 1024);
+        }
+    };
+    auto stage_b = [&](int h, int pb, const char* wb, int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const char* src = wb + (long)(kt * 2 + h) * T_HALF + (2 * wave + q) * 1024 + lane * 16;
+            glds16(src, st_lds + pb * T_BUF + (T_B0 + h) * T_HALF + q * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile) ----
+    int aoff[2][2], boff[2][2];                                   // [row-tile parity][kstep], [column tile][kstep]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int lr = wr * 64 + p * 16 + fr;
+            aoff[p][ks] = lr * 128 + (((ks * 4 + fq) ^ t_swz(lr)) << 4);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int lr = PERM ? wc * 32 + 8 * (fr >> 2) + 4 * ii + (fr & 3) : wc * 32 + ii * 16 + fr;
+            boff[ii][ks] = lr * 128 + (((ks * 4 + fq) ^ t_swz(lr)) << 4);
+        }
+    }
+
+    // ---- stream cursors (wave-uniform): s1 = K-tile g+1 (its A1), s2 = K-tile g+2 (A0, B0, B1) ----
+    int c_t = 0, c_kt = 0, c_row0;
+    const char* c_wb;
+    unit_of(0, c_row0, c_wb);
+    int s1_t = 0, s1_kt = 0, s1_row0 = c_row0;
+    const char* s1_wb = c_wb;
+    int s2_t = 0, s2_kt = 0, s2_row0 = c_row0;
+    const char* s2_wb = c_wb;
+    auto advance = [&](int& t, int& kt, int& row0, const char*& wb) {
+        if (kt + 1 < nkt) {
+            ++kt;
+        } else if (t + 1 < U) {
+            kt = 0;
+            ++t;
+            unit_of(t, row0, wb);
+        }                                                          // else: hold the last K-tile (harmless re-reads)
+    };
+
+    // prologue: K-tile 0 whole, K-tile 1 without its A1 (7 half-tiles, 14 LDS-DMA per wave)
+    stage_a(0, 0, s1_row0, 0);
+    stage_b(0, 0, s1_wb, 0);
+    stage_b(1, 0, s1_wb, 0);
+    stage_a(1, 0, s1_row0, 0);
+    advance(s1_t, s1_kt, s1_row0, s1_wb);                          // s1 -> K-tile 1
+    stage_a(0, 1, s1_row0, s1_kt);
+    stage_b(0, 1, s1_wb, s1_kt);
+    stage_b(1, 1, s1_wb, s1_kt);
+    s2_t = s1_t, s2_kt = s1_kt, s2_row0 = s1_row0, s2_wb = s1_wb;
+    advance(s2_t, s2_kt, s2_row0, s2_wb);                          // s2 -> K-tile 2
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // K-tile 0 has landed (this wave's share)
+    __syncthreads();                                               // ... everybody's; bias copy visible
+    if (wr == 1) T_BARRIER();                                      // wave row 1 runs one barrier behind row 0
+
+    f32x4 acc[4][8];
+    bf16x8 areg[4][2], breg0[2][2], breg1[2][2];
+
+    auto read_a = [&](int pb, int rh) {
+        const char* base = lds + pb * T_BUF + (T_A0 + rh) * T_HALF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                areg[tt][ks] = *reinterpret_cast<const bf16x8*>(base + (tt >> 1) * 4096 + aoff[tt & 1][ks]);
+    };
+    auto read_b = [&](int pb, int ch, bf16x8 (&br)[2][2]) {
+        const char* base = lds + pb * T_BUF + (T_B0 + ch) * T_HALF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+                br[ii][ks] = *reinterpret_cast<const bf16x8*>(base + boff[ii][ks]);
+    };
+    auto quadrant = [&](int rh, int ch, const bf16x8 (&br)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+                    acc[2 * ch + ii][4 * rh + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        br[ii][ks], areg[tt][ks], acc[2 * ch + ii][4 * rh + tt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    auto epilogue = [&](int row0, int col0) {
+        const int mrow = row0 + wr * 128 + fr;                     // + 16 t
+        if constexpr (PERM) {
+            const int ncol = col0 + wc * 64 + 8 * fq;              // + 32 h
+            auto emit = [&](int t, int h, const uint4* hq) {
+                const int m = mrow + 16 * t;
+                const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
+                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const long o = (long)m * N + ncol + 32 * h;
+                if (m >= M) return;
+                if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
+                    *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
+                        pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                    // the saved pre-activation is the bf16-rounded value; GELU sees the same rounded value
+                    uint32_t hp[4], up[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+                        const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                        up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
+                    }
+                    if (out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                    *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
+                } else {  // NEAT_EPI_GELU_BWD
+                    const uint32_t hp[4] = {hq->x, hq->y, hq->z, hq->w};
+                    uint32_t dp[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                        dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
+                    }
+                    *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+                }
+            };
+            if constexpr (EPI == NEAT_EPI_GELU_BWD) {
+                uint4 hq[8][2];                                    // the whole wave tile of h: 16 loads in flight
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    int m = mrow + 16 * t;
+                    m = m < M ? m : M - 1;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        hq[t][h] = *reinterpret_cast<const uint4*>(aux + (long)m * N + ncol + 32 * h);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) emit(t, h, &hq[t][h]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) emit(t, h, nullptr);
+            }
+        } else {
+            const int ncol = col0 + wc * 64 + 4 * fq;              // + 16 i
+            // residual rows are loaded two row tiles (8 loads) ahead of their use; res may alias out0 (in place):
+            // a lane only ever re-reads what it has not yet written
+            float4 rr[3][4];
+            auto load_res = [&](int t) {
+                int m = mrow + 16 * t;
+                m = m < M ? m : M - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rr[t % 3][i] = *reinterpret_cast<const float4*>(res + (long)m * N + ncol + 16 * i);
+            };
+            if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                load_res(0);
+                load_res(1);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                    if (t + 2 < 8) load_res(t + 2);
+                }
+                const int m = mrow + 16 * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 a4 = acc[i][t];
+                    float4 o4 = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                    if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
+                        const float4 r4 = rr[t % 3][i];
+                        o4.x += r4.x, o4.y += r4.y, o4.z += r4.z, o4.w += r4.w;
+                    }
+                    if (m < M) *reinterpret_cast<float4*>((float*)out0 + (long)m * N + ncol + 16 * i) = o4;
+                }
+            }
+        }
+    };
+
+    auto init_acc = [&](int col0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (HAS_BIAS) {
+                const int n = PERM ? col0 + wc * 64 + 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : col0 + wc * 64 + 16 * i + 4 * fq;
+                b0 = *reinterpret_cast<const f32x4*>(lds + T_BIAS + n * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[i][t] = b0;
+        }
+    };
+
+    // one K-tile = two merged phases of 32 MFMAs per wave; PB = LDS buffer of this K-tile.
+    //   MP0 reads B0 B1 A0 (16 ds_read_b128), MP1 reads A1 (8); B0/B1 stay in registers for MP1.
+    //   MP1 restages A0 B0 B1 (read in MP0, retired by the lgkmcnt(0) before MP0's barrier) for K-tile g+2,
+    //   the next MP0 restages A1: 6 + 2 LDS-DMA per wave, which balances the 8 + 16 fragment reads.
+    //   Waits (in-order vmcnt, LDS-DMA only in the loop): MP1 needs A0 B0 B1 of K-tile g+1 = everything but the
+    //   8 youngest (A1(g+1), A0 B0 B1(g+2)); MP0 needs A1 of its own K-tile = everything but the 8 youngest
+    //   (A0 B0 B1(g+1), A1(g+1)).  A buffer is read one phase after the wait that retires it.
+    auto ktile = [&](auto pb_tag) {
+        constexpr int PB = decltype(pb_tag)::value;
+        read_b(PB, 0, breg0);
+        read_b(PB, 1, breg1);
+        read_a(PB, 0);
+        stage_a(1, PB ^ 1, s1_row0, s1_kt);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T_BARRIER();
+        quadrant(0, 0, breg0);
+        quadrant(0, 1, breg1);
+        T_BARRIER();
+        read_a(PB, 1);
+        stage_a(0, PB, s2_row0, s2_kt);
+        stage_b(0, PB, s2_wb, s2_kt);
+        stage_b(1, PB, s2_wb, s2_kt);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T_BARRIER();
+        quadrant(1, 1, breg1);
+        quadrant(1, 0, breg0);
+        T_BARRIER();
+        advance(s1_t, s1_kt, s1_row0, s1_wb);
+        advance(s2_t, s2_kt, s2_row0, s2_wb);
+    };
+
+    const int G = U * nkt;
+    for (int g = 0; g < G; g += 2) {
+        if (c_kt == 0) init_acc((int)((c_wb - Wp) / wcb_bytes) << 8);
+        ktile(std::integral_constant<int, 0>{});
+        ktile(std::integral_constant<int, 1>{});
+        c_kt += 2;
+        if (c_kt == nkt) {
+            epilogue(c_row0, (int)((c_wb - Wp) / wcb_bytes) << 8);
+            c_kt = 0;
+            if (++c_t < U) unit_of(c_t, c_row0, c_wb);
+        }
+    }
+    if (wr == 0) T_BARRIER();                                      // pairs with wave row 1's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no LDS-DMA may land after the workgroup ends
+}
+
+// f32 weights -> bf16 in the tile256 LDS image: half-tile ((cb*nkt + kt)*2 + h) is 16 KiB = 128 rows x 8 chunks;
+// row lr holds column cb*256 + (lr>>5)*64 + h*32 + (lr&31), LDS chunk p holds k = kt*64 + (p ^ swz(lr))*8 .. +7
+__global__ void pack_weight_t256_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int K,
+                                        int transposed) {
+    const long total = (long)N * K / 8;
+    const int nkt = K >> 6;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)(u & 1023);
+        const long ht = u >> 10;
+        const int h = (int)(ht & 1);
+        const int kt = (int)((ht >> 1) % nkt);
+        const int cb = (int)((ht >> 1) / nkt);
+        const int lr = pos >> 3;
+        const int c = (pos & 7) ^ t_swz(lr);
+        const int n = cb * 256 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+        const int k0 = kt * 64 + c * 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 2 * j;
+            const float a = transposed ? src[(long)k * N + n] : src[(long)n * K + k];
+            const float b = transposed ? src[(long)(k + 1) * N + n] : src[(long)n * K + k + 1];
+            w[j] = pack2bf(a, b);
+        }
+        reinterpret_cast<uint4*>(dst)[u] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int EPI>
+static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
+                            const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS),
+                           "hipFuncSetAttribute(gemm_tile256)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const long units = (long)cdiv(M, 256) * (N / 256);
+    const int cus = num_cus();
+    const long want = (units + 7) / 8 * 8;
+    const int grid = (int)(want < cus ? want : cus);
+    hipLaunchKernelGGL((gemm_tile256_kernel<EPI>), dim3(grid), dim3(T_THREADS), T_LDS, s, A,
+                       reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K);
+    NEAT_LAUNCH_CHECK("neat_gemm_bf16(tile256)");
+    return NEAT_OK;
+}
+
 }  // namespace neat
 
 using namespace neat;
@@ -418,4 +816,62 @@ extern "C" int neat_gemm_bf16(const uint16_t* A, const uint16_t* W, const float*
         default:
             return set_error(NEAT_ERR_ARG, "neat_gemm_bf16: unknown epilogue %d", epilogue);
     }
+}
+
+// ---- tile256 entry points ----
+extern "C" int neat_pack_weight_bf16_t256(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream) {
+    NEAT_REQUIRE(src && dst, NEAT_ERR_ARG, "neat_pack_weight_bf16_t256: null pointer");
+    NEAT_REQUIRE(N > 0 && K > 0 && t256_shape_ok(N, K), NEAT_ERR_SHAPE,
+                 "neat_pack_weight_bf16_t256: N=%d K=%d (need N %% 256 == 0, K %% 128 == 0, N <= %d)", N, K, T_MAXN);
+    long g = ((long)N * K / 8 + 255) / 256;
+    hipLaunchKernelGGL(pack_weight_t256_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, K, transposed);
+    NEAT_LAUNCH_CHECK("neat_pack_weight_bf16_t256");
+    return NEAT_OK;
+}
+
+extern "C" int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* W, const float* bias, const float* res,
+                                   const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
+                                   void* stream) {
+    NEAT_REQUIRE(A && W, NEAT_ERR_ARG, "neat_gemm_bf16_t256: null operand");
+    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && t256_shape_ok(N, K), NEAT_ERR_SHAPE,
+                 "neat_gemm_bf16_t256: M=%d N=%d K=%d unsupported (need N %% 256 == 0, K %% 128 == 0, N <= %d)", M, N, K,
+                 T_MAXN);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case NEAT_EPI_BF16:
+            NEAT_REQUIRE(out0, NEAT_ERR_ARG, "neat_gemm_bf16_t256: out0 is null");
+            return launch_gemm_t256<NEAT_EPI_BF16>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        case NEAT_EPI_BIAS_BF16:
+            NEAT_REQUIRE(out0 && bias, NEAT_ERR_ARG, "neat_gemm_bf16_t256: BIAS_BF16 needs bias, out0");
+            return launch_gemm_t256<NEAT_EPI_BIAS_BF16>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        case NEAT_EPI_BIAS_RES_F32:
+            NEAT_REQUIRE(out0 && bias && res, NEAT_ERR_ARG, "neat_gemm_bf16_t256: BIAS_RES_F32 needs bias, res, out0");
+            return launch_gemm_t256<NEAT_EPI_BIAS_RES_F32>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        case NEAT_EPI_BIAS_GELU:
+            NEAT_REQUIRE(out1 && bias, NEAT_ERR_ARG, "neat_gemm_bf16_t256: BIAS_GELU needs bias, out1");
+            return launch_gemm_t256<NEAT_EPI_BIAS_GELU>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        case NEAT_EPI_GELU_BWD:
+            NEAT_REQUIRE(out0 && aux, NEAT_ERR_ARG, "neat_gemm_bf16_t256: GELU_BWD needs aux, out0");
+            return launch_gemm_t256<NEAT_EPI_GELU_BWD>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        case NEAT_EPI_F32:
+            NEAT_REQUIRE(out0, NEAT_ERR_ARG, "neat_gemm_bf16_t256: out0 is null");
+            return launch_gemm_t256<NEAT_EPI_F32>(A, W, bias, res, aux, out0, out1, M, N, K, s);
+        default:
+            return set_error(NEAT_ERR_ARG, "neat_gemm_bf16_t256: unknown epilogue %d", epilogue);
+    }
+}
+
+// Which of the two GEMMs a caller holding BOTH weight layouts should launch (1 = tile256).  Measured inside the
+// TTA step on MI355X (profiles/r01_*): tile256 wins where the epilogue only stores and the grid fills the chip for
+// at least ~1.5 rounds of 256 x 256 units (c_fc 247 vs 274 us, the bf16 dgrad GEMMs 81 vs 91 us on average);
+// the residual / GELU' epilogues (which load as much as they store), the qkv projection and small M stay on
+// gemm_panel_kernel (two workgroups per CU overlap one's epilogue with the other's main loop).
+extern "C" int neat_gemm_prefers_t256(int M, int N, int K, int epilogue) {
+    if (M <= 0 || N <= 0 || K <= 0 || !t256_shape_ok(N, K)) return 0;
+    if (!(epilogue == NEAT_EPI_BF16 || epilogue == NEAT_EPI_BIAS_GELU)) return 0;
+    const long units = (long)cdiv(M, 256) * (N / 256);
+    const int cus = num_cus();
+    const long rounds = (units + cus - 1) / cus;
+    return units * 2 >= 3L * cus && units * 4 >= 3 * rounds * cus;
 }

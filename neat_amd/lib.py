@@ -24,6 +24,9 @@ SIGNATURES = {
     "neat_ln_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _I, _P]),
     "neat_pack_weight_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_gemm_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "neat_pack_weight_bf16_t256": (_I, [_P, _P, _I, _I, _I, _P]),
+    "neat_gemm_bf16_t256": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "neat_gemm_prefers_t256": (_I, [_I, _I, _I, _I]),
     "neat_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_pack_plan": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -6,6 +6,7 @@ raise RuntimeError on any failure -- there is no eager fallback.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -105,27 +106,42 @@ def ln_bwd(dy, x, gamma, mean, rstd, dres=None, want_f32=True, want_bf16=True, d
 
 # ---- GEMM ----
 class PackedWeight:
-    """A frozen weight matrix in the kernel's MFMA-fragment order (see include/neat_hip.h).
+    """A frozen weight matrix packed for the GEMM kernels (see include/neat_hip.h): ``data`` in MFMA-fragment order
+    (neat_gemm_bf16) and, for shapes the tile256 kernel takes, ``data256`` in its LDS image (neat_gemm_bf16_t256).
     ``N`` / ``K`` are the LOGICAL dims of out[M,N] = A[M,K] @ Wl[N,K]^T."""
 
-    __slots__ = ("data", "N", "K")
+    __slots__ = ("data", "data256", "N", "K")
 
-    def __init__(self, data, N, K):
-        self.data, self.N, self.K = data, N, K
+    def __init__(self, data, N, K, data256=None):
+        self.data, self.N, self.K, self.data256 = data, N, K, data256
+
+
+def t256_shape_ok(N, K):
+    return N % 256 == 0 and K % 128 == 0 and N <= 8192
+
+
+# NEAT_GEMM=panel | t256 forces one kernel wherever its shape rules allow (A/B timing); default: the library's choice
+_GEMM_FORCE = os.environ.get("NEAT_GEMM", "")
 
 
 def pack_weight(w, transposed=False) -> PackedWeight:
-    """w fp32 [N,K] (transposed=False) or fp32 [K,N] whose transpose is the logical matrix (dgrad)."""
+    """w fp32 [N,K] (transposed=False) or fp32 [K,N] whose transpose is the logical matrix (dgrad).  Both kernel
+    layouts are kept (N*K bf16 each): which kernel runs is decided per call from M and the epilogue."""
     if w.dim() != 2:
         raise RuntimeError("pack_weight: expected a 2-D weight")
     N, K = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     dst = torch.empty(N * K, dtype=bf16, device=w.device)
     lib.call("neat_pack_weight_bf16", _p(w, f32, "w"), _p(dst), N, K, int(transposed), _stream())
-    return PackedWeight(dst, N, K)
+    dst256 = None
+    if t256_shape_ok(N, K) and _GEMM_FORCE != "panel":
+        dst256 = torch.empty(N * K, dtype=bf16, device=w.device)
+        lib.call("neat_pack_weight_bf16_t256", _p(w, f32, "w"), _p(dst256), N, K, int(transposed), _stream())
+    return PackedWeight(dst, N, K, dst256)
 
 
-def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None, out1=None):
-    """out[M,N] = epilogue(A[M,K] @ Wl[N,K]^T); allocates outputs that are not passed in."""
+def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None, out1=None, kernel=None):
+    """out[M,N] = epilogue(A[M,K] @ Wl[N,K]^T); allocates outputs that are not passed in.
+    kernel: None = the library's choice (neat_gemm_prefers_t256), "panel" / "t256" = that kernel (tests, timing)."""
     M, K = A.shape
     N = W.N
     if W.K != K:
@@ -144,14 +160,20 @@ def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None,
         raise RuntimeError("gemm: residual shape mismatch")
     if aux is not None and (aux.dtype != bf16 or aux.shape[1] != N or aux.shape[0] < M):
         raise RuntimeError("gemm: aux shape/dtype mismatch")
-    args = (_p(A, bf16, "A"), _p(W.data, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0), _p(out1), M, N, K, epilogue,
-            _stream())
+    force = kernel or _GEMM_FORCE
+    if force == "t256" and kernel and W.data256 is None:
+        raise RuntimeError(f"gemm: no tile256 layout for packed [{W.N},{W.K}] (need N % 256 == 0, K % 128 == 0)")
+    use256 = W.data256 is not None and force != "panel" and (
+        force == "t256" or lib.load().neat_gemm_prefers_t256(M, N, K, epilogue) == 1)
+    fn = "neat_gemm_bf16_t256" if use256 else "neat_gemm_bf16"
+    args = (_p(A, bf16, "A"), _p(W.data256 if use256 else W.data, bf16, "W"), _p(bias), _p(res), _p(aux), _p(out0),
+            _p(out1), M, N, K, epilogue, _stream())
     t = KERNEL_TIMER
     if t is not None and t.match("gemm", epilogue, M, N, K):
         with t.region(M, N, K):
-            lib.call("neat_gemm_bf16", *args)
+            lib.call(fn, *args)
     else:
-        lib.call("neat_gemm_bf16", *args)
+        lib.call(fn, *args)
     return out0, out1
 
 

@@ -75,8 +75,15 @@ SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 128)
           (5000, 528, 384), (40000, 512, 512)]
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES)
-def test_gemm_epilogues(M, N, K):
+def _kernels(N, K):
+    return ["panel", "t256"] if ops.t256_shape_ok(N, K) else ["panel"]
+
+
+GEMM_CASES = [(M, N, K, kern) for (M, N, K) in SHAPES for kern in _kernels(N, K)]
+
+
+@pytest.mark.parametrize("M,N,K,kern", GEMM_CASES)
+def test_gemm_epilogues(M, N, K, kern):
     A = bf(torch.randn(M, K, generator=g(1)))
     W = bf(torch.randn(N, K, generator=g(2)) * K ** -0.5)
     bias = torch.randn(N, generator=g(3)) * 0.1
@@ -84,23 +91,23 @@ def test_gemm_epilogues(M, N, K):
     ref = A.float() @ W.float().t()
     Ad, Wd, bd, rd = A.to(DEV), ops.pack_weight(W.float().to(DEV)), bias.to(DEV), res.to(DEV)
     tol = 6e-3
-    o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16)
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16, kernel=kern)
     assert rel_l2(o.float().cpu(), ref) < tol
-    o, _ = ops.gemm(Ad, Wd, lib.EPI_F32)
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_F32, kernel=kern)
     assert rel_l2(o.cpu(), ref) < 1e-5
-    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_BF16, bias=bd)
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_BF16, bias=bd, kernel=kern)
     assert rel_l2(o.float().cpu(), ref + bias) < tol
-    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=rd)
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=rd, kernel=kern)
     assert rel_l2(o.cpu(), ref + bias + res) < 1e-5
     # in-place residual
     r2 = rd.clone()
-    ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=r2, out0=r2)
+    ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=r2, out0=r2, kernel=kern)
     assert rel_l2(r2.cpu(), ref + bias + res) < 1e-5
-    h, u = ops.gemm(Ad, Wd, lib.EPI_BIAS_GELU, bias=bd)
+    h, u = ops.gemm(Ad, Wd, lib.EPI_BIAS_GELU, bias=bd, kernel=kern)
     assert rel_l2(h.float().cpu(), ref + bias) < tol
     assert rel_l2(u.float().cpu(), O.quick_gelu(h.float().cpu())) < tol
     aux = bf(torch.randn(M, N, generator=g(5)))
-    o, _ = ops.gemm(Ad, Wd, lib.EPI_GELU_BWD, aux=aux.to(DEV))
+    o, _ = ops.gemm(Ad, Wd, lib.EPI_GELU_BWD, aux=aux.to(DEV), kernel=kern)
     assert rel_l2(o.float().cpu(), ref * O.quick_gelu_grad(aux.float())) < tol
 
 
@@ -110,8 +117,12 @@ def test_gemm_exact_small_integers():
     K = 256
     A = torch.eye(M, K)
     W = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 7) % 61 - 30.0
-    o, _ = ops.gemm(bf(A).to(DEV), ops.pack_weight(W.to(DEV)), lib.EPI_F32)
-    assert torch.equal(o.cpu(), (A @ W.t()))
+    for kern in ("panel", "t256"):
+        o, _ = ops.gemm(bf(A).to(DEV), ops.pack_weight(W.to(DEV)), lib.EPI_F32, kernel=kern)
+        assert torch.equal(o.cpu(), (A @ W.t()))
+        o, _ = ops.gemm(bf(A).to(DEV), ops.pack_weight(W.t().contiguous().to(DEV), transposed=True), lib.EPI_F32,
+                        kernel=kern)
+        assert torch.equal(o.cpu(), (A @ W.t()))
     A2 = torch.randint(-4, 5, (333, 256), generator=g(1)).float()
     W2 = torch.randint(-4, 5, (80, 256), generator=g(2)).float()
     o, _ = ops.gemm(bf(A2).to(DEV), ops.pack_weight(W2.to(DEV)), lib.EPI_F32)
@@ -121,9 +132,11 @@ def test_gemm_exact_small_integers():
     assert torch.equal(o.cpu(), A2 @ W2.t())
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 300 + 37, 528, 512), (128 * 260, 256, 768), (128 * 257 + 1, 512, 1536),
-                                   (78848, 2048, 512)])
-def test_gemm_exact_at_full_size(M, N, K):
+@pytest.mark.parametrize("M,N,K,kern", [(128 * 300 + 37, 528, 512, "panel"), (128 * 260, 256, 768, "panel"),
+                                        (128 * 257 + 1, 512, 1536, "panel"), (78848, 2048, 512, "panel"),
+                                        (128 * 260, 256, 768, "t256"), (128 * 257 + 1, 512, 1536, "t256"),
+                                        (78848, 2048, 512, "t256"), (59136 + 77, 512, 2048, "t256")])
+def test_gemm_exact_at_full_size(M, N, K, kern):
     """Full-size launches (many units per workgroup, ragged rows, idle waves at N = 528, the c_fc shape) on
     small-integer operands: every bf16 output is exact, so a late or missing LDS piece cannot hide."""
     A = torch.randint(-1, 2, (M, K), generator=g(1)).float()
@@ -133,13 +146,19 @@ def test_gemm_exact_at_full_size(M, N, K):
     ref = (A.to(DEV) @ W.to(DEV).t())
     assert float(ref.abs().max()) + 3 <= 256          # exactly representable in bf16
     for _ in range(2):                                 # twice: the second launch sees warm caches / other timing
-        o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16)
+        o, _ = ops.gemm(Ad, Wd, lib.EPI_BF16, kernel=kern)
         assert torch.equal(o.float(), ref)
-        o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_BF16, bias=bd)
+        o, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_BF16, bias=bd, kernel=kern)
         assert torch.equal(o.float(), ref + bd)
-        h, u = ops.gemm(Ad, Wd, lib.EPI_BIAS_GELU, bias=bd)
+        h, u = ops.gemm(Ad, Wd, lib.EPI_BIAS_GELU, bias=bd, kernel=kern)
         assert torch.equal(h.float(), ref + bd)
         assert rel_l2(u.float().cpu(), O.quick_gelu((ref + bd).cpu())) < 6e-3
+        # fp32 outputs with the residual read in place, and the GELU' epilogue on an exact aux
+        r2 = torch.ones(M, N, device=DEV)
+        ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bd, res=r2, out0=r2, kernel=kern)
+        assert torch.equal(r2, ref + bd + 1.0)
+        o, _ = ops.gemm(Ad, Wd, lib.EPI_GELU_BWD, aux=torch.zeros(M, N, dtype=torch.bfloat16, device=DEV), kernel=kern)
+        assert torch.equal(o.float(), (ref * 0.5))     # QuickGELU'(0) = 0.5
 
 
 def test_gemm_rejects_bad_shapes():
