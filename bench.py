@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0             # HBM3E peak, same guide
 # FETCH_SIZE doubled as the guide prescribes for gfx950 wide streaming reads -- the LN kernels in the same
 # passes confirm the factor: ln_fwd reports 80.8 MB for a 161.5 MB read).  Keyed by (M, N, K); a launch mix
 # that was not profiled reports traffic = null.
-PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 156523.71 + 634498.45) * 1024)}
+PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 121616.71 + 631209.59) * 1024)}
 
 
 def parse():
@@ -195,7 +195,12 @@ def main():
     flops_row_step = text_tower_flops_per_row_step(cfg, L)
     shapes = set(timer.shapes)
     traffic = PMC_TRAFFIC_BYTES.get(next(iter(shapes))) if len(shapes) == 1 else None
-    roofline = dict(bound="hbm", kernel="gemm_panel_kernel<NEAT_EPI_BIAS_GELU> (c_fc: M=4*B*77, N=4C, K=C)",
+    shape0 = next(iter(shapes)) if shapes else (0, 0, 0)
+    t256 = bool(shapes) and lib.load().neat_gemm_prefers_t256(*shape0, lib.EPI_BIAS_GELU) == 1
+    if not t256:
+        traffic = None                                             # the PMC passes profiled the tile256 launch
+    roofline = dict(bound="hbm", kernel=("gemm_tile256_kernel" if t256 else "gemm_panel_kernel") +
+                    "<NEAT_EPI_BIAS_GELU> (c_fc: M=4*B*77, N=4C, K=C)",
                     achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                     traffic=traffic, launches=nl, avg_launch_ms=round(avg_ms, 4),
                     algorithmic_bytes_per_launch=int(avg_bytes), mfma_tflops=round(tfs, 1),

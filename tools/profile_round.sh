@@ -1,0 +1,16 @@
+# Round profile recipe (run on the GPU box from the repo root): kernel-trace stats, then one --pmc pass per counter.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof; rm -rf $O; mkdir -p $O
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --skip-gallery-encode --no-packed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS > $O/kt.log 2>&1 || exit 1
+cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --skip-gallery-encode --no-packed > $O/pmc_$c.log 2>&1 || exit 1
+  python3 tools/summarize_pmc.py $(ls $O/pmc_$c/*/*counter_collection.csv | head -1) $O/bench_pmc_$(echo $c | tr A-Z a-z).csv || exit 1
+done
+timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_auto.txt
+NEAT_GEMM=panel timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_panel.txt
+NEAT_GEMM=t256 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_t256.txt
+rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+head -8 $O/bench_kernel_stats.csv | cut -c1-160; head -6 $O/bench_pmc_fetch_size.csv | cut -c1-200; head -6 $O/bench_pmc_write_size.csv | cut -c1-200
