@@ -59,6 +59,10 @@ int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const fl
 /* dgamma[c] (+)= sum_b partial[b,0,c]; dbeta[c] (+)= sum_b partial[b,1,c]  (fixed order -> deterministic) */
 int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, float* dgamma, float* dbeta,
                          int accumulate, void* stream);
+/* the same for `count` LayerNorms in one launch (a whole backward pass): partial [count, nblk, 2, cols],
+ * dst = DEVICE array of 2*count device pointers {dgamma_0, dbeta_0, dgamma_1, ...}; same fixed summation order */
+int neat_ln_bwd_finalize_batched(const float* partial, int nblk, int cols, int count, float* const* dst,
+                                 int accumulate, void* stream);
 
 /* ---- bf16 MFMA GEMM: nn.Linear / MHA projections, open_clip/transformer.py:209-213,227-229 ---- */
 /* Frozen weights are packed ONCE into MFMA-fragment order (bf16).  Logical matrix Wl[N,K]:

@@ -199,6 +199,29 @@ __global__ __launch_bounds__(64 * LNF_SLICES) void ln_bwd_finalize_kernel(const 
     }
 }
 
+// the same reduction for `count` LayerNorms at once: blockIdx.y = which; dst[2*which] = dgamma, dst[2*which+1] = dbeta
+__global__ __launch_bounds__(64 * LNF_SLICES) void ln_bwd_finalize_batched_kernel(const float* __restrict__ partial,
+                                                                                 int nblk, int cols,
+                                                                                 float* const* __restrict__ dst,
+                                                                                 int accumulate) {
+    __shared__ float red[LNF_SLICES][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const float* src = partial + (long)blockIdx.y * nblk * 2 * cols;
+    float s = 0.f;
+    if (c < 2 * cols)
+        for (int b = slice; b < nblk; b += LNF_SLICES) s += src[(long)b * 2 * cols + c];
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && c < 2 * cols) {
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNF_SLICES; ++k) s += red[k][lane];
+        float* d = (c < cols) ? dst[2 * blockIdx.y] + c : dst[2 * blockIdx.y + 1] + (c - cols);
+        *d = accumulate ? (*d + s) : s;
+    }
+}
+
 static int ln_grid(int rows) {
     int g = cdiv(rows, LN_WAVES);
     return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -261,5 +284,16 @@ extern "C" int neat_ln_bwd_finalize(const float* partial, int nblk, int cols, fl
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(2 * cols, 64)), dim3(64 * LNF_SLICES), 0, (hipStream_t)stream,
                        partial, nblk, cols, dgamma, dbeta, accumulate);
     NEAT_LAUNCH_CHECK("neat_ln_bwd_finalize");
+    return NEAT_OK;
+}
+
+extern "C" int neat_ln_bwd_finalize_batched(const float* partial, int nblk, int cols, int count, float* const* dst,
+                                            int accumulate, void* stream) {
+    NEAT_REQUIRE(partial && dst, NEAT_ERR_ARG, "neat_ln_bwd_finalize_batched: null pointer");
+    NEAT_REQUIRE(nblk > 0 && cols > 0 && count > 0 && count <= 65535, NEAT_ERR_SHAPE,
+                 "neat_ln_bwd_finalize_batched: bad shape");
+    hipLaunchKernelGGL(ln_bwd_finalize_batched_kernel, dim3(cdiv(2 * cols, 64), count), dim3(64 * LNF_SLICES), 0,
+                       (hipStream_t)stream, partial, nblk, cols, dst, accumulate);
+    NEAT_LAUNCH_CHECK("neat_ln_bwd_finalize_batched");
     return NEAT_OK;
 }

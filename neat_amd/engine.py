@@ -70,16 +70,24 @@ class Stack:
         forward (M = nseq*L rows, or cu[nseq] rows of a packed batch).  grads[i] = dict(ln1_w, ln1_b, ln2_w,
         ln2_b) receive d(gamma), d(beta)."""
         M = dxf.shape[0]
-        for w, s, g in zip(reversed(self.blocks), reversed(saved), reversed(grads)):
+        C = dxf.shape[1]
+        # the per-block partial sums of d(gamma), d(beta) of all 2*layers LayerNorms are reduced by ONE launch at the end
+        nl = len(self.blocks)
+        parts = torch.empty(2 * nl, ops.ln_bwd_blocks(M), 2, C, dtype=f32, device=dxf.device)
+        dsts = []
+        for j, (w, s, g) in enumerate(zip(reversed(self.blocks), reversed(saved), reversed(grads))):
             dh, _ = ops.gemm(dxb, w.wT["proj"], lib.EPI_GELU_BWD, aux=s["h"])
             dy2, _ = ops.gemm(dh, w.wT["fc"], lib.EPI_BF16)
-            dxf, dxb = ops.ln_bwd(dy2, s["x1"][:M], w.ln2_w, s["mu2"], s["rs2"], dres=dxf, dgamma=g["ln2_w"],
-                                  dbeta=g["ln2_b"], accumulate=accumulate, inplace_res=True)
+            dxf, dxb = ops.ln_bwd(dy2, s["x1"][:M], w.ln2_w, s["mu2"], s["rs2"], dres=dxf, inplace_res=True,
+                                  partial=parts[2 * j])
+            dsts.append((g["ln2_w"], g["ln2_b"]))
             do, _ = ops.gemm(dxb, w.wT["o"], lib.EPI_BF16)
             dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal, cu=cu)
             dy1, _ = ops.gemm(dqkv, w.wT["qkv"], lib.EPI_BF16)
-            dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, dgamma=g["ln1_w"],
-                                  dbeta=g["ln1_b"], accumulate=accumulate, inplace_res=True)
+            dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, inplace_res=True,
+                                  partial=parts[2 * j + 1])
+            dsts.append((g["ln1_w"], g["ln1_b"]))
+        ops.ln_bwd_finalize_batched(parts, dsts, accumulate=accumulate)
         return dxf, dxb
 
 

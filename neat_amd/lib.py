@@ -22,6 +22,7 @@ SIGNATURES = {
     "neat_ln_bwd_blocks": (_I, [_I]),
     "neat_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "neat_ln_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _I, _P]),
+    "neat_ln_bwd_finalize_batched": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "neat_pack_weight_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_gemm_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_pack_weight_bf16_t256": (_I, [_P, _P, _I, _I, _I, _P]),

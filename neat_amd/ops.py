@@ -86,22 +86,56 @@ def ln_fwd(x, gamma, beta, eps=1e-5, out_bf16=True, out_f32=False, save_stats=Tr
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dres=None, want_f32=True, want_bf16=True, dgamma=None, dbeta=None,
-           accumulate=False, inplace_res=False):
-    """Returns (dx_f32, dx_bf16).  If dgamma/dbeta are given they receive (or accumulate) the parameter grads."""
+           accumulate=False, inplace_res=False, partial=None):
+    """Returns (dx_f32, dx_bf16).  If dgamma/dbeta are given they receive (or accumulate) the parameter grads.
+    ``partial`` (fp32 [ln_bwd_blocks(rows), 2, cols], caller-owned): leave the per-block partial sums there and skip
+    the finalize pass -- the caller reduces a whole backward pass at once with ``ln_bwd_finalize_batched``."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dxf = (dres if (inplace_res and dres is not None) else torch.empty(x.shape, dtype=f32, device=x.device)) \
         if want_f32 else None
     dxb = torch.empty(x.shape, dtype=bf16, device=x.device) if want_bf16 else None
-    partial = None
-    if dgamma is not None:
-        nblk = lib.load().neat_ln_bwd_blocks(rows)
-        partial = torch.empty(nblk, 2, cols, dtype=f32, device=x.device)
+    deferred = partial is not None
+    if dgamma is not None and not deferred:
+        partial = torch.empty(ln_bwd_blocks(rows), 2, cols, dtype=f32, device=x.device)
+    if deferred and tuple(partial.shape) != (ln_bwd_blocks(rows), 2, cols):
+        raise RuntimeError(f"ln_bwd: partial shape {tuple(partial.shape)} != {(ln_bwd_blocks(rows), 2, cols)}")
     lib.call("neat_ln_bwd", _p(dy, bf16, "dy"), _p(x, f32, "x"), _p(gamma, f32, "gamma"), _p(mean, f32), _p(rstd, f32),
-             _p(dres, f32), _p(dxf), _p(dxb), _p(partial), rows, cols, _stream())
-    if dgamma is not None:
+             _p(dres, f32), _p(dxf), _p(dxb), _p(partial, f32, "partial") if partial is not None else None, rows, cols,
+             _stream())
+    if dgamma is not None and not deferred:
         lib.call("neat_ln_bwd_finalize", _p(partial), partial.shape[0], cols, _p(dgamma, f32, "dgamma"),
                  _p(dbeta, f32, "dbeta"), int(accumulate), _stream())
     return dxf, dxb
+
+
+def ln_bwd_blocks(rows):
+    return lib.load().neat_ln_bwd_blocks(rows)
+
+
+_PTR_TABLES = {}
+
+
+def ln_bwd_finalize_batched(partials, dsts, accumulate=False):
+    """partials fp32 [count, nblk, 2, cols]; dsts = [(dgamma_0, dbeta_0), ...] fp32 [cols] tensors: one launch reduces
+    them all (fixed order, deterministic).  The device table of destination pointers is cached per destination set."""
+    count, nblk, _, cols = partials.shape
+    if len(dsts) != count:
+        raise RuntimeError("ln_bwd_finalize_batched: one (dgamma, dbeta) pair per partial block expected")
+    ptrs = []
+    for dg, db in dsts:
+        for t in (dg, db):
+            if t.dtype != f32 or t.numel() != cols or not t.is_contiguous() or t.device != partials.device:
+                raise RuntimeError("ln_bwd_finalize_batched: destinations must be contiguous fp32 [cols] on the device")
+            ptrs.append(t.data_ptr())
+    key = (partials.device.index, tuple(ptrs))
+    table = _PTR_TABLES.get(key)
+    if table is None:
+        if len(_PTR_TABLES) > 64:
+            _PTR_TABLES.clear()
+        table = torch.tensor(ptrs, dtype=torch.int64).to(partials.device)
+        _PTR_TABLES[key] = table
+    lib.call("neat_ln_bwd_finalize_batched", _p(partials, f32, "partials"), nblk, cols, count, _p(table), int(accumulate),
+             _stream())
 
 
 # ---- GEMM ----

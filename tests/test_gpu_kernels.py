@@ -70,6 +70,29 @@ def test_ln_is_deterministic():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_ln_bwd_finalize_batched_equals_per_layer():
+    """One launch over all LayerNorms of a backward pass == the per-LayerNorm finalize, bit for bit."""
+    rows, cols, count = 4000, 512, 6
+    x = torch.randn(rows, cols, generator=g(3)).to(DEV)
+    gam = (1 + 0.1 * torch.randn(cols, generator=g(4))).to(DEV)
+    _, _, mu, rs = ops.ln_fwd(x, gam, gam)
+    parts = torch.empty(count, ops.ln_bwd_blocks(rows), 2, cols, device=DEV)
+    ref, dsts = [], []
+    for j in range(count):
+        dy = bf(torch.randn(rows, cols, generator=g(10 + j))).to(DEV)
+        dg = torch.zeros(cols, device=DEV); db = torch.zeros(cols, device=DEV)
+        ops.ln_bwd(dy, x, gam, mu, rs, dgamma=dg, dbeta=db)
+        ref.append((dg, db))
+        ops.ln_bwd(dy, x, gam, mu, rs, partial=parts[j])
+        dsts.append((torch.full((cols,), 7.0, device=DEV), torch.full((cols,), 7.0, device=DEV)))
+    ops.ln_bwd_finalize_batched(parts, dsts)
+    for (dg, db), (eg, eb) in zip(dsts, ref):
+        assert torch.equal(dg, eg) and torch.equal(db, eb)
+    ops.ln_bwd_finalize_batched(parts, dsts, accumulate=True)
+    for (dg, db), (eg, eb) in zip(dsts, ref):
+        assert torch.equal(dg, eg + eg) and torch.equal(db, eb + eb)
+
+
 # ------------------------------------------------------------------ GEMM
 SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 128), (512, 512, 2048), (77, 1536, 768),
           (5000, 528, 384), (40000, 512, 512)]
