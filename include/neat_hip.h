@@ -90,6 +90,16 @@ int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* Wp, const float* bias
                         void* stream);
 int neat_gemm_prefers_t256(int M, int N, int K, int epilogue);
 
+/* ---- image preprocessing of the TTA gallery loader (reference src/data/__init__.py:14-20: torchvision
+ * Resize((S,S), BICUBIC) on a PIL image -> ToTensor -> Normalize; the resize is Pillow's Image.resize, restated
+ * bit-exactly: horizontal then vertical 8-bit pass, antialiased bicubic, 22-bit fixed-point coefficients) ---- */
+/* src u8 [H, W, 3] (RGB, row-major) -> dst f32 [3, S, S] = ((resized / 255) - mean[c]) / std[c].
+ * workspace: neat_image_preprocess_ws_bytes(H, W, S) bytes of device memory (coefficient tables + the 8-bit
+ * intermediate), caller-owned, 256-B aligned. */
+long neat_image_preprocess_ws_bytes(int H, int W, int S);
+int neat_image_preprocess(const uint8_t* src, int H, int W, float* dst, int S, float mean0, float mean1, float mean2,
+                          float std0, float std1, float std2, void* workspace, void* stream);
+
 /* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
 /* qkv bf16 [rows, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [rows, C];
  * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL).

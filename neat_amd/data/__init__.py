@@ -1,0 +1,71 @@
+"""Datasets and loaders of the TTA path (reference src/data/__init__.py:12-73), MI355X-first.
+
+Same entry points (``create_dataset``, ``create_sampler``, ``create_loader``) and the same dataset attributes the TTA
+loop reads (``.dataset.text`` / ``.dataset.image``).  Differences, on purpose:
+  * the image transform does not run in the dataset: the dataset yields decoded uint8 [H, W, 3] images and
+    ``GpuImageLoader`` resizes / normalises each on the GPU with ``neat_image_preprocess`` (Pillow-exact bicubic),
+    so a gallery batch arrives on the device as fp32 [b, 3, S, S];
+  * ``create_loader`` passes ``shuffle`` only when there is no sampler (the reference passes both, which
+    ``DataLoader`` rejects -- SURVEY.md section 0).
+"""
+import torch
+from torch.utils.data import DataLoader
+
+from .. import ops
+from .coco_negated_dataset import coco_negated_retrieval_eval_image, coco_negated_retrieval_eval_text
+from .utils import pre_caption
+
+__all__ = ["create_dataset", "create_sampler", "create_loader", "GpuImageLoader", "pre_caption",
+           "coco_negated_retrieval_eval_image", "coco_negated_retrieval_eval_text"]
+
+
+def create_dataset(dataset_name, input_filename, resize=384):
+    if dataset_name != 'coco_negated':
+        raise NotImplementedError(f"create_dataset: dataset '{dataset_name}' is outside the built path "
+                                  "(only 'coco_negated'; video decoding is not part of it)")
+    kw = dict(csv_file=input_filename, sep=',', img_key='filepath', caption_key_pos='pos_captions',
+              caption_key_neg='neg_captions')
+    text = coco_negated_retrieval_eval_text(None, **kw)
+    image = coco_negated_retrieval_eval_image(None, **kw)
+    image.resize = text.resize = resize
+    return text, image
+
+
+def create_sampler(datasets, shuffles, num_tasks, global_rank):
+    return [torch.utils.data.DistributedSampler(d, num_replicas=num_tasks, rank=global_rank, shuffle=s)
+            for d, s in zip(datasets, shuffles)]
+
+
+def _list_collate(batch):
+    return [b[0] for b in batch], torch.tensor([b[1] for b in batch], dtype=torch.int64)
+
+
+class GpuImageLoader:
+    """Iterates a DataLoader of (uint8 [H, W, 3] image, index) and yields (fp32 [b, 3, S, S] on ``device``, index)."""
+
+    def __init__(self, loader, size, device=None):
+        self.loader, self.size = loader, size
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dataset = loader.dataset
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for images, index in self.loader:
+            out = torch.empty(len(images), 3, self.size, self.size, dtype=torch.float32, device=self.device)
+            for i, im in enumerate(images):
+                ops.image_preprocess(im.to(self.device, non_blocking=True), self.size, out=out[i])
+            yield out, index
+
+
+def create_loader(datasets, samplers, batch_size, num_workers, is_trains, collate_fns, device=None):
+    loaders = []
+    for dataset, sampler, bs, n_worker, is_train, collate_fn in zip(datasets, samplers, batch_size, num_workers,
+                                                                    is_trains, collate_fns):
+        is_image = isinstance(dataset, coco_negated_retrieval_eval_image)
+        loader = DataLoader(dataset, batch_size=bs, num_workers=n_worker, pin_memory=True, sampler=sampler,
+                            shuffle=(sampler is None), collate_fn=_list_collate if (is_image and collate_fn is None)
+                            else collate_fn, drop_last=False)
+        loaders.append(GpuImageLoader(loader, getattr(dataset, "resize", 224), device) if is_image else loader)
+    return loaders

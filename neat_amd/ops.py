@@ -211,6 +211,28 @@ def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None,
     return out0, out1
 
 
+# ---- image preprocessing ----
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def image_preprocess(img_u8, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None):
+    """img_u8 uint8 [H, W, 3] on the GPU -> fp32 [3, size, size]: Pillow-exact antialiased bicubic resize, / 255,
+    Normalize (reference src/data/__init__.py:14-20)."""
+    if img_u8.dim() != 3 or img_u8.shape[2] != 3:
+        raise RuntimeError(f"image_preprocess: expected uint8 [H, W, 3], got {tuple(img_u8.shape)}")
+    H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+    if out is None:
+        out = torch.empty(3, size, size, dtype=f32, device=img_u8.device)
+    elif tuple(out.shape) != (3, size, size):
+        raise RuntimeError("image_preprocess: out must be fp32 [3, size, size]")
+    nbytes = lib.load().neat_image_preprocess_ws_bytes(H, W, size)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=img_u8.device)
+    lib.call("neat_image_preprocess", _p(img_u8, torch.uint8, "img"), H, W, _p(out, f32, "out"), size,
+             float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _p(ws), _stream())
+    return out
+
+
 # ---- attention ----
 def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None):
     """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0]."""
