@@ -87,3 +87,23 @@ def test_normalize_oracle_equals_torch():
     t = torch.from_numpy(u).permute(2, 0, 1).to(torch.float32).div(255)          # ToTensor
     t = t.sub_(torch.tensor(IO.CLIP_MEAN).view(3, 1, 1)).div_(torch.tensor(IO.CLIP_STD).view(3, 1, 1))   # Normalize
     assert np.array_equal(IO.to_tensor_normalize(u), t.numpy())
+
+
+def test_tokenizer_matches_reference():
+    """Token ids of our BPE implementation == the reference tokenizer's (tests/golden/tokenizer.json).  Needs the
+    external merge table; skipped where it is not installed (the GPU box has no reference checkout)."""
+    from neat_amd.open_clip import tokenizer as T
+    try:
+        path = T.default_bpe()
+    except FileNotFoundError:
+        pytest.skip("CLIP BPE merge table not available")
+    g = json.load(open(os.path.join(HERE, "golden", "tokenizer.json")))
+    tok = T.SimpleTokenizer(path)
+    assert (tok.vocab_size, tok.sot_token_id, tok.eot_token_id) == (g["vocab_size"], g["sot"], g["eot"])
+    for c in g["cases"]:
+        assert tok.encode(c["text"]) == c["ids"], c["text"]
+        assert tok(c["text"])[0].tolist() == c["ctx77"]
+        assert tok(c["text"], 16)[0].tolist() == c["ctx16"]
+        assert tok.decode(c["ids"]) == c["decoded"]
+    batch = tok([c["text"] for c in g["cases"]])
+    assert batch.shape == (len(g["cases"]), 77) and batch.dtype.is_floating_point is False
