@@ -273,11 +273,31 @@ def cpu_baseline(a, cfg):
     st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
     t0 = time.perf_counter()
     for _ in range(a.tta_steps):
-        O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)
+        losses_c, idx_c, S_c = O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)[:3]
     dt = time.perf_counter() - t0
-    return dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, kind="port",
-                sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, {a.model}, fp32 torch CPU oracle, "
-                       f"{dt:.1f} s")
+    out = dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, kind="port",
+               sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, {a.model}, fp32 torch CPU oracle, "
+                      f"{dt:.1f} s")
+    # the same sample through the HIP path: recall@1 of both legs on the produced score rows (synthetic ground
+    # truth: caption r <-> gallery item r % 64) and how often their top-1 items agree
+    from neat_amd import open_clip as oc, train_TTA as T
+    from neat_amd.optim import AdamW
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model = oc.create_model(a.model, device=dev)
+    model.load_state_dict(synth.synth_state_dict(a.model, 0), strict=True)
+    oc.freeze_parameters(model, False)
+    opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+    toks_d = [x.to(dev) for x in toks]
+    for _ in range(a.tta_steps):
+        losses_g, idx_g, S_g = T.tta_step(model, opt, toks_d, G.to(dev), 0.03, 0.07)
+    truth = torch.arange(Bc) % 64
+    S_g = S_g.float().cpu()
+    out["recall_at_1"] = dict(gpu=round(float((S_g.argmax(1) == truth).float().mean()), 4),
+                              cpu=round(float((S_c.argmax(1) == truth).float().mean()), 4),
+                              top1_agreement=round(float((S_g.argmax(1) == S_c.argmax(1)).float().mean()), 4),
+                              loss_rel_diff=round(float(abs(losses_g.sum().item() - float(sum(losses_c))) /
+                                                        abs(float(sum(losses_c)))), 6))
+    return out
 
 
 if __name__ == "__main__":
