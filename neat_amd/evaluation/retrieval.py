@@ -92,7 +92,9 @@ def retrieval_eval(model, data, args, scores, tokenizer=None):
     def put(prefix, m):
         for d, key in (("t2i", "image_retrieval"), ("i2t", "text_retrieval")):
             for k in (1, 5, 10):
-                results[f"{prefix}-{d}-R@{k}"] = m[f"{key}_recall@{k}"]
+                # the reference spells exactly one key with an underscore (retrieval.py:117): 'msrvtt-i2t_R@1'
+                sep = "_" if (prefix, d, k) == ("msrvtt", "i2t", 1) else "-"
+                results[f"{prefix}-{d}{sep}R@{k}"] = m[f"{key}_recall@{k}"]
 
     video = getattr(args, "video", False)
     plain, negated = ("msrvtt-retrieval", "msrvtt-negated-retrieval") if video else ("coco-retrieval", "coco-negated-retrieval")

@@ -423,6 +423,23 @@ def test_offline_eval_and_mcq_match_oracle():
     b2 = [(imgs[i:i + 6], [o[i:i + 6] for o in opts[:2]], answers[i:i + 6] % 2) for i in range(0, n_img, 6)]
     mb2 = MQ.evaluate_binary_mcq_model(model, _ListLoader(b2, n_img), args, tok)
     assert 0.0 <= mb2["total_accuracy"] <= 1.0
+    # the driver the CLI calls after train_one_epoch (evaluation/utils.py:9-66): result keys + one results.jsonl line
+    import json as _json
+    import tempfile
+    from neat_amd.evaluation.utils import evaluate
+    with tempfile.TemporaryDirectory() as d:
+        args2 = types.SimpleNamespace(device=DEV, batch_size=4, video=False, save_logs=True, checkpoint_path=d, wandb=False)
+        online = scores.to(DEV).contiguous()
+        data = {"coco-negated-retrieval": types.SimpleNamespace(dataloader=_ListLoader(batches, n_img)),
+                "synthetic-mcq": types.SimpleNamespace(dataloader=_ListLoader(mb, n_img))}
+        res = evaluate(model, data, 0, args2, score_matrix_t2i=online, tokenizer=tok)
+        want = {f"{p}-coco-negated-{dd}-R@{k}" for p in ("online", "offline") for dd in ("t2i", "i2t") for k in (1, 5, 10)}
+        assert want <= set(res) and "synthetic-mcq-total_accuracy" in res
+        for k, v in ref.items():                                  # online metrics on the exact fp32 scores = the oracle's
+            dd, kk = ("t2i" if k.startswith("image") else "i2t"), k.split("@")[1]
+            assert abs(res[f"online-coco-negated-{dd}-R@{kk}"] - v) < 1e-6
+        lines = open(os.path.join(d, "results.jsonl")).read().strip().split("\n")
+        assert len(lines) == 1 and set(_json.loads(lines[0])) == set(res)
 
 
 def test_video_pooling_matches_oracle():
