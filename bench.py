@@ -269,7 +269,7 @@ def cpu_baseline(a, cfg):
     t = cfg["text_cfg"]
     Bc = a.cpu_sample
     toks = synth.synth_caption_sets(Bc, t["context_length"], t["vocab_size"], 1000)
-    G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"]), dim=-1)
+    G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"], generator=torch.Generator().manual_seed(7)), dim=-1)
     st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
     t0 = time.perf_counter()
     for _ in range(a.tta_steps):
