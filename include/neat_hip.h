@@ -99,6 +99,12 @@ int neat_gemm_prefers_t256(int M, int N, int K, int epilogue);
 long neat_image_preprocess_ws_bytes(int H, int W, int S);
 int neat_image_preprocess(const uint8_t* src, int H, int W, float* dst, int S, float mean0, float mean1, float mean2,
                           float std0, float std1, float std2, void* workspace, void* stream);
+/* n images of mixed sizes in one launch set (a gallery batch): srcs = DEVICE array of n device pointers (u8 [H_i,W_i,3]),
+ * hw = DEVICE int32 [n][2] = (H_i, W_i); max_h / max_w = the largest of them (host values); dst f32 [n, 3, S, S];
+ * workspace = n * neat_image_preprocess_ws_bytes(max(max_h,S), max(max_w,S), S) bytes.  Bit-identical to n single calls. */
+int neat_image_preprocess_batch(const uint8_t* const* srcs, const int32_t* hw, int n, int max_h, int max_w, float* dst,
+                                int S, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                                void* workspace, void* stream);
 
 /* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
 /* qkv bf16 [rows, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [rows, C];

@@ -3,7 +3,8 @@
 Same entry points (``create_dataset``, ``create_sampler``, ``create_loader``) and the same dataset attributes the TTA
 loop reads (``.dataset.text`` / ``.dataset.image``).  Differences, on purpose:
   * the image transform does not run in the dataset: the dataset yields decoded uint8 [H, W, 3] images and
-    ``GpuImageLoader`` resizes / normalises each on the GPU with ``neat_image_preprocess`` (Pillow-exact bicubic),
+    ``GpuImageLoader`` resizes / normalises a whole batch of mixed-size images on the GPU in one launch set
+    (``neat_image_preprocess_batch``, Pillow-exact bicubic),
     so a gallery batch arrives on the device as fp32 [b, 3, S, S];
   * ``create_loader`` passes ``shuffle`` only when there is no sampler (the reference passes both, which
     ``DataLoader`` rejects -- SURVEY.md section 0).
@@ -53,10 +54,8 @@ class GpuImageLoader:
 
     def __iter__(self):
         for images, index in self.loader:
-            out = torch.empty(len(images), 3, self.size, self.size, dtype=torch.float32, device=self.device)
-            for i, im in enumerate(images):
-                ops.image_preprocess(im.to(self.device, non_blocking=True), self.size, out=out[i])
-            yield out, index
+            on_dev = [im.to(self.device, non_blocking=True).contiguous() for im in images]
+            yield ops.image_preprocess_batch(on_dev, self.size), index
 
 
 def create_loader(datasets, samplers, batch_size, num_workers, is_trains, collate_fns, device=None):

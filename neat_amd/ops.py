@@ -233,6 +233,31 @@ def image_preprocess(img_u8, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None):
     return out
 
 
+def image_preprocess_batch(images, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None):
+    """images: list of uint8 [H_i, W_i, 3] GPU tensors (mixed sizes) -> fp32 [n, 3, size, size] in ONE launch set;
+    bit-identical to ``image_preprocess`` per image."""
+    n = len(images)
+    if n == 0:
+        raise RuntimeError("image_preprocess_batch: empty batch")
+    dev = images[0].device
+    for im in images:
+        if im.dim() != 3 or im.shape[2] != 3 or im.dtype != torch.uint8 or im.device != dev or not im.is_contiguous():
+            raise RuntimeError("image_preprocess_batch: expected contiguous uint8 [H, W, 3] tensors on one GPU")
+    hw = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+    max_h, max_w = max(h for h, _ in hw), max(w for _, w in hw)
+    if out is None:
+        out = torch.empty(n, 3, size, size, dtype=f32, device=dev)
+    elif tuple(out.shape) != (n, 3, size, size):
+        raise RuntimeError("image_preprocess_batch: out must be fp32 [n, 3, size, size]")
+    table = torch.tensor([im.data_ptr() for im in images] + [v for p in hw for v in p], dtype=torch.int64).to(dev)
+    ptrs, hw_d = table[:n], table[n:].to(torch.int32)
+    stride = lib.load().neat_image_preprocess_ws_bytes(max(max_h, size), max(max_w, size), size)
+    ws = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    lib.call("neat_image_preprocess_batch", _p(ptrs), _p(hw_d), n, max_h, max_w, _p(out, f32, "out"), size,
+             float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _p(ws), _stream())
+    return out
+
+
 # ---- attention ----
 def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None):
     """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0]."""

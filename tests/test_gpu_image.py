@@ -28,6 +28,17 @@ def test_image_preprocess_bit_exact(h, w, s):
     assert np.array_equal(out, IO.to_tensor_normalize(resized))
 
 
+def test_image_preprocess_batch_equals_single_calls():
+    """Mixed sizes in one launch set (up- and down-scaling, one-axis passes, H == W == S) == per-image calls, bit for bit."""
+    rng = np.random.default_rng(2)
+    shapes = [(480, 640), (224, 224), (100, 300), (224, 500), (300, 224), (17, 19), (640, 427), (1, 1), (500, 375)]
+    ims = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).to(DEV) for h, w in shapes]
+    for s in (224, 32):
+        got = ops.image_preprocess_batch(ims, s)
+        for i, im in enumerate(ims):
+            assert torch.equal(got[i], ops.image_preprocess(im, s)), (shapes[i], s)
+
+
 def test_gpu_loader_matches_host_transform(tmp_path):
     """create_dataset / create_loader end to end: CSV -> decoded images -> GPU preprocessing == Pillow + torch ops."""
     from PIL import Image

@@ -30,3 +30,19 @@ for (h, w, s) in [(480, 640, 224), (427, 640, 224), (2000, 3000, 224)]:
     cpu = (time.perf_counter() - t0) / m
     print(f"{h}x{w}->{s}: GPU {dt*1e6:7.1f} us/image wall ({dev_us:7.1f} us device span), {1/dt:8.0f} img/s, "
           f"{alg/dev_us/1e3:6.2f} GB/s algorithmic; Pillow+numpy on 1 host core {cpu*1e3:6.2f} ms/image = {1/cpu:6.0f} img/s")
+
+# batched form: a gallery batch of 256 COCO-sized images of mixed sizes in one launch set
+sizes = [(480, 640), (427, 640), (640, 480), (500, 375), (375, 500), (333, 500), (480, 640), (640, 427)]
+ims = [torch.from_numpy(rng.integers(0, 256, sizes[i % 8] + (3,), dtype=np.uint8)).to(dev) for i in range(256)]
+out = torch.empty(256, 3, 224, 224, device=dev)
+for _ in range(3): ops.image_preprocess_batch(ims, 224, out=out)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 20
+e0.record()
+for _ in range(n): ops.image_preprocess_batch(ims, 224, out=out)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / n
+alg = sum(3 * h * w for h, w in [sizes[i % 8] for i in range(256)]) + 256 * 12 * 224 * 224
+print(f"batch of 256 mixed COCO sizes -> 224: {us:8.1f} us per batch = {us/256:6.2f} us/image, {256/us*1e6:9.0f} img/s, "
+      f"{alg/us/1e3:7.1f} GB/s algorithmic")
