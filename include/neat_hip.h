@@ -106,6 +106,16 @@ int neat_image_preprocess_batch(const uint8_t* const* srcs, const int32_t* hw, i
                                 int S, float mean0, float mean1, float mean2, float std0, float std1, float std2,
                                 void* workspace, void* stream);
 
+/* ---- video-frame preprocessing of the MSR-VTT gallery loader (replaces the host transform of src/data/__init__.py:22-26:
+ * ConvertImageDtype(float32) -> Resize((S,S), BICUBIC, antialias=True) on a tensor -> Normalize; the resize is ATen's
+ * upsample_bicubic2d_aa: separable float convolution, cubic a = -0.5, horizontal pass first, result not clamped) ---- */
+/* src u8 [T, H, W, 3] (decoder layout: frames, rows, RGB) -> dst f32 [T, 3, S, S] = (resize(src / 255) - mean[c]) / std[c].
+ * workspace: neat_frames_preprocess_ws_bytes(T, H, W, S) bytes (coefficient tables + the fp32 intermediate [T,3,H,S]),
+ * caller-owned, 256-B aligned. */
+long neat_frames_preprocess_ws_bytes(int T, int H, int W, int S);
+int neat_frames_preprocess(const uint8_t* src, int T, int H, int W, float* dst, int S, float mean0, float mean1, float mean2,
+                           float std0, float std1, float std2, void* workspace, void* stream);
+
 /* ---- attention core of nn.MultiheadAttention, open_clip/transformer.py:202,227-229,655-661 ---- */
 /* qkv bf16 [rows, 3*C] (per token: q | k | v, heads of 64 inside each C); out bf16 [rows, C];
  * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL).

@@ -31,6 +31,8 @@ SIGNATURES = {
     "neat_image_preprocess_ws_bytes": (_L, [_I, _I, _I]),
     "neat_image_preprocess": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
     "neat_image_preprocess_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "neat_frames_preprocess_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "neat_frames_preprocess": (_I, [_P, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _P, _P]),
     "neat_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_pack_plan": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -258,6 +258,23 @@ def image_preprocess_batch(images, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=N
     return out
 
 
+def frames_preprocess(frames_u8, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=None):
+    """frames_u8 uint8 [T, H, W, 3] on the GPU (decoder layout) -> fp32 [T, 3, size, size]: / 255, antialiased bicubic
+    resize as torch does it on float tensors, Normalize (reference src/data/__init__.py:22-26)."""
+    if frames_u8.dim() != 4 or frames_u8.shape[3] != 3:
+        raise RuntimeError(f"frames_preprocess: expected uint8 [T, H, W, 3], got {tuple(frames_u8.shape)}")
+    T, H, W = (int(v) for v in frames_u8.shape[:3])
+    if out is None:
+        out = torch.empty(T, 3, size, size, dtype=f32, device=frames_u8.device)
+    elif tuple(out.shape) != (T, 3, size, size):
+        raise RuntimeError("frames_preprocess: out must be fp32 [T, 3, size, size]")
+    nbytes = lib.load().neat_frames_preprocess_ws_bytes(T, H, W, size)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=frames_u8.device)
+    lib.call("neat_frames_preprocess", _p(frames_u8, torch.uint8, "frames"), T, H, W, _p(out, f32, "out"), size,
+             float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _p(ws), _stream())
+    return out
+
+
 # ---- attention ----
 def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None):
     """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0]."""

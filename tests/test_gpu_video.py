@@ -1,0 +1,72 @@
+"""GPU parity of neat_frames_preprocess (through the C ABI): bit-identical to the oracle's float restatement, and within
+2e-6 / 1e-5 of torch's own CPU operator (the code the reference's video transform calls); the MSR-VTT loader end to end."""
+import numpy as np
+import pytest
+import torch
+
+from neat_amd import ops
+from oracle import video_oracle as VO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MEAN, STD = ops.CLIP_MEAN, ops.CLIP_STD
+
+
+def _torch_host_transform(fr, s):
+    x = torch.from_numpy(fr).permute(0, 3, 1, 2).to(torch.float32) / 255
+    x = torch.nn.functional.interpolate(x, size=(s, s), mode="bicubic", align_corners=False, antialias=True)
+    return (x - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
+
+
+@pytest.mark.parametrize("t,h,w,s", [(4, 240, 320, 224), (1, 37, 53, 32), (3, 224, 224, 224), (2, 100, 70, 224),
+                                     (2, 224, 300, 224), (2, 300, 224, 224), (1, 1, 1, 8), (4, 360, 640, 224),
+                                     (1, 1080, 1920, 224)])
+def test_frames_preprocess_matches_oracle_and_torch(t, h, w, s):
+    rng = np.random.default_rng(t * 7 + h * 1000 + w)
+    fr = rng.integers(0, 256, (t, h, w, 3), dtype=np.uint8)
+    if h > 30:
+        fr[0, : h // 3] = 255
+        fr[0, h // 3: h // 2, ::2] = 0
+    out = ops.frames_preprocess(torch.from_numpy(fr).to(DEV), s).cpu()
+    assert out.shape == (t, 3, s, s)
+    assert (out - _torch_host_transform(fr, s)).abs().max().item() <= 1e-5
+    if h * w <= 360 * 640:                                        # the numpy oracle is slow on huge inputs
+        assert np.array_equal(out.numpy(), VO.preprocess_frames(fr, s, MEAN, STD))
+
+
+def test_frames_preprocess_rejects_bad_shapes():
+    with pytest.raises(RuntimeError):
+        ops.frames_preprocess(torch.zeros(4, 8, 8, dtype=torch.uint8, device=DEV), 8)
+    with pytest.raises(RuntimeError):
+        ops.frames_preprocess(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=DEV), 8,
+                              out=torch.empty(1, 3, 9, 9, device=DEV))
+
+
+def test_video_loader_and_pooled_embedding(tmp_path):
+    """CSV -> msrvtt datasets -> GpuVideoLoader -> [b, T, 3, S, S] == host transform of the sampled frames; clips of
+    different sizes in one batch take the per-clip route."""
+    from neat_amd import data as D
+    from neat_amd.data.frame_sampler import UniformFrameSampler
+    rng = np.random.default_rng(5)
+    clips, rows = [], []
+    row = '"[\'a man is not singing\']","[\'a man\']","[\'singing\']","[\'a man is singing\']"'
+    for i, (n, h, w) in enumerate([(30, 48, 64), (9, 48, 64), (17, 48, 64), (12, 40, 56)]):
+        c = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        np.save(tmp_path / f"v{i}.npy", c)
+        clips.append(c)
+        rows.append(f"{tmp_path / f'v{i}.npy'},{row}")
+    csv_file = tmp_path / "v.csv"
+    csv_file.write_text("filepath,captions,pos_captions,neg_captions,inverted_captions\n" + "\n".join(rows) + "\n")
+    text_ds, video_ds = D.create_dataset("msrvtt_negated", str(csv_file), 32)
+    assert len(text_ds) == 4 and len(video_ds) == 4
+    _, loader = D.create_loader([text_ds, video_ds], [None, None], [4, 2], [0, 0], [False, False], [None, None], device=DEV)
+    assert isinstance(loader, D.GpuVideoLoader) and loader.dataset is video_ds
+    seen = 0
+    for batch, index in loader:
+        assert batch.shape[1:] == (4, 3, 32, 32) and batch.is_cuda
+        for b, i in zip(batch.cpu(), index.tolist()):
+            c = clips[i]
+            want = _torch_host_transform(c[UniformFrameSampler(4)(0, len(c) - 1)], 32)
+            assert (b - want).abs().max().item() <= 1e-5
+            seen += 1
+    assert seen == 4
