@@ -70,3 +70,66 @@ def test_video_loader_and_pooled_embedding(tmp_path):
             assert (b - want).abs().max().item() <= 1e-5
             seen += 1
     assert seen == 4
+
+
+def test_video_csv_to_scores_flow(tmp_path):
+    """Config 4 end to end on a tiny model: msrvtt CSV -> datasets -> loaders (GPU frame transform) -> VideoCLIP ->
+    train_one_epoch.  Scores are bit-identical to the same epoch fed with pre-tokenised tensors and clips transformed by
+    the oracle on the host, and the pooled gallery features match the oracle's encode_video."""
+    import types
+    from torch.utils.data import SequentialSampler
+    from neat_amd import data as D, open_clip as oc, synth, train_TTA as T
+    from neat_amd.data.frame_sampler import UniformFrameSampler
+    from neat_amd.optim import AdamW
+
+    cfg = synth.get_cfg("neat-tiny")
+    ctx, vocab, S = cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"], cfg["vision_cfg"]["image_size"]
+    rng = np.random.default_rng(11)
+    words = ["sing", "dance", "cook", "drive", "swim", "talk", "run", "paint"]
+    rows, clips = [], []
+    for i in range(5):
+        c = rng.integers(0, 256, (int(rng.integers(5, 40)), 36, 48, 3), dtype=np.uint8)
+        np.save(tmp_path / f"v{i}.npy", c)
+        clips.append(c)
+        x, y = words[i % 8], words[(i + 3) % 8]
+        caps, pos, neg, inv = [f"a man does {x} but does not {y}"], [f"a man does {x}"], [f"{y}"], [f"a man does {y} but does not {x}"]
+        rows.append(f'{tmp_path / f"v{i}.npy"},"{caps!r}","{pos!r}","{neg!r}","{inv!r}"')
+    csv_file = tmp_path / "v.csv"
+    csv_file.write_text("filepath,captions,pos_captions,neg_captions,inverted_captions\n" + "\n".join(rows) + "\n")
+
+    def toy_tokenizer(texts):
+        out = torch.zeros(len(texts), ctx, dtype=torch.long)
+        for r, t in enumerate(texts):
+            ids = [vocab - 2] + [1 + (sum(map(ord, w)) * 7 + len(w)) % (vocab - 3) for w in t.split(" ")][: ctx - 2] + [vocab - 1]
+            out[r, :len(ids)] = torch.tensor(ids)
+        return out
+
+    def run(text_loader, video_loader, tokenizer):
+        model = oc.VideoCLIP(oc.create_model("neat-tiny", device=DEV))
+        model.clip.load_state_dict(synth.synth_state_dict("neat-tiny", 3), strict=True)
+        oc.freeze_parameters(model, False)
+        opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+        args = types.SimpleNamespace(distributed=False, tta_only_visual=False, name="neat", tta_steps=2,
+                                     tta_temperature=0.03, tta_temperature2=0.07)
+        return T.train_one_epoch(model, tokenizer, text_loader, video_loader, opt, torch.device(DEV), args)[1]
+
+    text_ds, video_ds = D.create_dataset("msrvtt_negated", str(csv_file), S)
+    loaders = D.create_loader([text_ds, video_ds], [SequentialSampler(text_ds), SequentialSampler(video_ds)], [8, 2],
+                              [0, 0], [False, False], [None, None], device=DEV)
+    t2i = run(loaders[0], loaders[1], toy_tokenizer)
+    assert t2i.shape == (5, 5) and (t2i > -100).all()
+
+    class Fake:
+        def __init__(self, batches, n, attr):
+            self.batches, self.dataset = batches, types.SimpleNamespace(**{attr: list(range(n))})
+
+        def __iter__(self):
+            return iter(self.batches)
+
+    host = torch.stack([torch.from_numpy(VO.preprocess_frames(c[UniformFrameSampler(4)(0, len(c) - 1)], S, MEAN, STD))
+                        for c in clips])
+    vb = [(host[i:i + 2], torch.arange(i, min(i + 2, 5))) for i in range(0, 5, 2)]
+    tb = [(toy_tokenizer(text_ds.text), toy_tokenizer(text_ds.pos_text), toy_tokenizer(text_ds.neg_text),
+           toy_tokenizer(text_ds.inv_text), torch.arange(5))]
+    ref = run(Fake(tb, 5, "text"), Fake(vb, 5, "image"), lambda x: x)
+    assert torch.equal(t2i, ref)
