@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0             # HBM3E peak, same guide
 # FETCH_SIZE doubled as the guide prescribes for gfx950 wide streaming reads -- the LN kernels in the same
 # passes confirm the factor: ln_fwd reports 80.8 MB for a 161.5 MB read).  Keyed by (M, N, K); a launch mix
 # that was not profiled reports traffic = null.
-PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 121616.71 + 631209.59) * 1024)}
+PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 124711.91 + 631331.20) * 1024)}
 
 
 def parse():
