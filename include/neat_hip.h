@@ -83,7 +83,8 @@ int neat_gemm_bf16(const uint16_t* A, const uint16_t* Wp, const float* bias, con
  * cb*256 + (lr>>5)*64 + h*32 + (lr&31), chunk p holds k = kt*64 + (p ^ swz(lr))*8 .. +7,
  * swz(lr) = ((lr>>1)&7) ^ (((lr>>4)&1)<<1).  Same arguments, epilogues and results as neat_gemm_bf16 (bf16 operands,
  * fp32 accumulation in k order per 32-k step).  neat_gemm_prefers_t256 returns 1 where this form is the faster one
- * on MI355X (store-only epilogues on grids of >= 1.5 rounds of units); a caller keeps the layout(s) it will use. */
+ * on MI355X (store-only epilogues on grids of >= 1.5 rounds of units, every epilogue from 768 x 3072 weights on); a
+ * caller keeps the layout(s) it will use. */
 int neat_pack_weight_bf16_t256(const float* src, uint16_t* dst, int N, int K, int transposed, void* stream);
 int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                         const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,

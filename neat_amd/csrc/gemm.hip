@@ -864,12 +864,15 @@ extern "C" int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* W, const f
 
 // Which of the two GEMMs a caller holding BOTH weight layouts should launch (1 = tile256).  Measured inside the
 // TTA step on MI355X (profiles/r01_*): tile256 wins where the epilogue only stores and the grid fills the chip for
-// at least ~1.5 rounds of 256 x 256 units (c_fc 247 vs 274 us, the bf16 dgrad GEMMs 81 vs 91 us on average);
-// the residual / GELU' epilogues (which load as much as they store), the qkv projection and small M stay on
-// gemm_panel_kernel (two workgroups per CU overlap one's epilogue with the other's main loop).
+// at least ~1.5 rounds of 256 x 256 units (c_fc 247 vs 274 us, the bf16 dgrad GEMMs 81 vs 91 us on average; the qkv
+// projection: neutral at C = 512, +0.8 % of the ViT-L-14 step).  The residual / GELU' epilogues (which load as much
+// as they store) stay on gemm_panel_kernel (two workgroups per CU overlap one's epilogue with the other's main loop)
+// for the ViT-B weights and move to tile256 from 768 x 3072 weights on (ViT-L-14: c_proj 405 vs 445 us, the GELU'
+// dgrad 352 vs 371 us; +2.1 % of that step).
 extern "C" int neat_gemm_prefers_t256(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || !t256_shape_ok(N, K)) return 0;
-    if (!(epilogue == NEAT_EPI_BF16 || epilogue == NEAT_EPI_BIAS_GELU)) return 0;
+    const bool store_only = epilogue == NEAT_EPI_BF16 || epilogue == NEAT_EPI_BIAS_GELU || epilogue == NEAT_EPI_BIAS_BF16;
+    if (!store_only && (long)N * K < 768L * 3072) return 0;
     const long units = (long)cdiv(M, 256) * (N / 256);
     const int cus = num_cus();
     const long rounds = (units + cus - 1) / cus;

@@ -7,10 +7,11 @@ from neat_amd import lib, ops
 dev = "cuda"
 B = int(os.environ.get("B", 256))
 M4, M3 = 4 * B * 77, 3 * B * 77
-shapes = [("qkv  fwd BIAS_BF16", lib.EPI_BIAS_BF16, M4, 1536, 512), ("out  fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, 512, 512),
-          ("fc   fwd BIAS_GELU", lib.EPI_BIAS_GELU, M4, 2048, 512), ("proj fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, 512, 2048),
-          ("dproj bwd GELU_BWD", lib.EPI_GELU_BWD, M3, 2048, 512), ("dfc  bwd BF16", lib.EPI_BF16, M3, 512, 2048),
-          ("do   bwd BF16", lib.EPI_BF16, M3, 512, 512), ("dqkv bwd BF16", lib.EPI_BF16, M3, 512, 1536)]
+C = int(os.environ.get("C", 512))                 # text width: 512 = ViT-B-32 / B-16, 768 = ViT-L-14
+shapes = [("qkv  fwd BIAS_BF16", lib.EPI_BIAS_BF16, M4, 3 * C, C), ("out  fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, C, C),
+          ("fc   fwd BIAS_GELU", lib.EPI_BIAS_GELU, M4, 4 * C, C), ("proj fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, C, 4 * C),
+          ("dproj bwd GELU_BWD", lib.EPI_GELU_BWD, M3, 4 * C, C), ("dfc  bwd BF16", lib.EPI_BF16, M3, C, 4 * C),
+          ("do   bwd BF16", lib.EPI_BF16, M3, C, C), ("dqkv bwd BF16", lib.EPI_BF16, M3, C, 3 * C)]
 g = torch.Generator(device=dev).manual_seed(0)
 cases = []
 for name, epi, M, N, K in shapes:
