@@ -88,7 +88,8 @@ def main():
     local = local % max(ndev, 1)          # rehearsal of N ranks on fewer GPUs (NEAT_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force = os.environ.get("NEAT_FORCE_COLLECTIVES", "") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force:
         import torch.distributed as dist
         backend = os.environ.get("NEAT_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI
         if backend == "nccl":
@@ -132,7 +133,7 @@ def main():
             del img
     torch.cuda.synchronize()
     gallery_s = time.perf_counter() - t0
-    G = T._all_gather_rows(G_local, n_img, world) if world > 1 else G_local
+    G = T._all_gather_rows(G_local, n_img, world) if (world > 1 or force) else G_local
 
     _dbg('gallery done')
     # ---- synthetic caption batches, resident in HBM ----
@@ -150,12 +151,12 @@ def main():
 
     def run_batch(i):
         for _ in range(a.tta_steps):
-            losses, idx, S = T.tta_step(model, opt, batches[i], G, 0.03, 0.07, world, rank)
+            losses, idx, S = T.tta_step(model, opt, batches[i], G, 0.03, 0.07, world, rank, global_rows=B * world)
         score[i * B:(i + 1) * B] = S
         return losses
 
     def barrier():
-        if world > 1:
+        if world > 1 or force:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,10 +164,16 @@ def main():
     if os.environ.get('NEAT_BENCH_DEBUG'):
         import faulthandler
         faulthandler.dump_traceback_later(45, exit=True)
+    # the warm-up batches run with the event timer ON, so that the first use of timing events (a one-off stall of
+    # ~50 ms in the first process on a fresh box, tools/cold_start.py) is not inside the timed region; their events
+    # are discarded
+    timer.enabled = a.warmup > 0
     for i in range(a.warmup):
         run_batch(i)
         _dbg(f'warmup {i} done')
     barrier()
+    timer.events.clear()
+    timer.shapes.clear()
     _dbg('timed region starts')
     timer.enabled = True
     t0 = time.perf_counter()
@@ -176,7 +183,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     _dbg('timed region done')
-    if world > 1:
+    if world > 1 or force:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -253,7 +260,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, cfg)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

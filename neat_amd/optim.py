@@ -26,7 +26,10 @@ class AdamW(torch.optim.Optimizer):
             raise RuntimeError("neat_amd.optim.AdamW: parameters must be on the GPU")
         n = sum(p.numel() for p in params)
         self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # two spare floats behind the gradients: the data-parallel step sends its two row-summed loss terms with the
+        # gradient in ONE all-reduce over grad_buf
+        self.grad_buf = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self.flat_grad = self.grad_buf[:n]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = 0

@@ -20,6 +20,8 @@ from __future__ import annotations
 import logging
 from typing import Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -42,6 +44,11 @@ def tta_loss(text_feat, pos_text_feat, inv_text_feat, coarse_img_feat, T1, T2):
     return ops.tta_loss_fwd_bwd(text_feat, pos_text_feat, inv_text_feat, text_feat, coarse_img_feat, T1, T2, 0)
 
 
+# NEAT_FORCE_COLLECTIVES=1: run every collective of the data-parallel step even at world size 1 (a one-GPU rehearsal of the
+# RCCL call path: process group, all_gather of padded row shards, all_reduce of the flat LN gradient)
+FORCE_COLLECTIVES = os.environ.get("NEAT_FORCE_COLLECTIVES", "") == "1"
+
+
 def _shard(n: int, world: int, rank: int):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
@@ -52,6 +59,10 @@ def _all_gather_rows(x, n_total: int, world: int):
     """Concatenate row shards of (possibly) different sizes from all ranks, in rank order."""
     sizes = [_shard(n_total, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
+    if all(hi - lo == mx for lo, hi in sizes):                    # even shards: one output tensor, no padding, no cat
+        out = torch.empty(world * mx, *x.shape[1:], dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        return out
     pad = torch.zeros(mx, *x.shape[1:], dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
     out = [torch.empty_like(pad) for _ in range(world)]
@@ -72,9 +83,11 @@ def _ln_grad_views(model):
     return grads
 
 
-def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0):
+def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global_rows=None):
     """One inner step (train_TTA.py:133-147) on this rank's row shard.  tokens4 = (text,pos,neg,inv) int64
-    [Bl, L] on the GPU.  Returns (losses[3] tensor, coarse idx, sims_matrix) for the local rows."""
+    [Bl, L] on the GPU.  Returns (losses[3] tensor, coarse idx, sims_matrix) for the local rows.
+    global_rows: rows of the global batch when the caller knows them (shards cut by ``_shard``); without it the
+    ranks add up their row counts, which costs a collective and a host synchronisation per step."""
     text, pos, neg, inv = tokens4
     Bl = text.shape[0]
     tower = model._text_tower()
@@ -82,27 +95,40 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0):
                                packed=bool(getattr(model, "pack_tokens", False)))
     t, p, v, n = feats[:Bl], feats[Bl:2 * Bl], feats[2 * Bl:3 * Bl], feats[3 * Bl:]
     coarse, idx, S = ops.coarse_align(t, p, n, gallery)
-    if world > 1:
-        B = torch.tensor([Bl], device=t.device)
-        dist.all_reduce(B)
-        B = int(B.item())
+    if world > 1 or FORCE_COLLECTIVES:
+        if global_rows is None:
+            B = torch.tensor([Bl], device=t.device)
+            dist.all_reduce(B)
+            B = int(B.item())
+        else:
+            B = int(global_rows)
         row0 = _shard(B, world, rank)[0]
-        t_all = _all_gather_rows(t, B, world)
-        c_all = _all_gather_rows(coarse, B, world)
+        D = t.shape[1]
+        tc_all = _all_gather_rows(torch.cat([t, coarse], dim=1), B, world)     # one collective for both
+        t_all, c_all = tc_all[:, :D].contiguous(), tc_all[:, D:].contiguous()
     else:
         B, row0, t_all, c_all = Bl, 0, t, coarse
     losses, dt, dp, dv = ops.tta_loss_fwd_bwd(t, p, v, t_all, c_all, T1, T2, row0)
     grads = _ln_grad_views(model)
     tower.backward(ctx, torch.cat([dt, dp, dv], dim=0), grads, accumulate=False)
-    if world > 1:
-        flat = getattr(optimizer, "flat_grad", None)
-        if flat is not None:
-            dist.all_reduce(flat)
+    if world > 1 or FORCE_COLLECTIVES:
+        buf = getattr(optimizer, "grad_buf", None)
+        if buf is not None:
+            # neat_amd.optim.AdamW: gradients + the two row-summed loss terms travel as ONE collective.  An all-gather
+            # of the 98-KB buffers and a local sum in rank order instead of an all-reduce: every rank adds the same
+            # numbers in the same order (bit-identical parameters on all ranks by construction), and through
+            # torch.distributed on this stack the all-gather costs no host time while an all_reduce call blocks the
+            # host for 1.7 ms (tools/rccl_probe.py), which the launch-bound tail of the step cannot hide.
+            buf[-2:].copy_(losses[1:])
+            gathered = torch.empty(world, buf.numel(), dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(gathered.view(-1), buf)
+            torch.sum(gathered, dim=0, out=buf)
+            losses[1:].copy_(buf[-2:])
         else:
             for g in grads:
                 for x in g.values():
                     dist.all_reduce(x)
-        dist.all_reduce(losses[1:])      # sr / triplet are sums over local rows; entropy is already global
+            dist.all_reduce(losses[1:])      # sr / triplet are sums over local rows; entropy is already global
     optimizer.step()
     optimizer.zero_grad()
     return losses, idx, S
@@ -135,7 +161,7 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
         lo, hi = _shard(Bt, world, rank)
         local = [x[lo:hi].contiguous() for x in toks]
         for _ in range(args.tta_steps):
-            losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank)
+            losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt)
         le, ls, lt = losses.tolist()
         logging.info(f"\tloss_entropy: {le:.3f}, loss_sr: {ls:.3f}, loss_tri: {lt:.3f}")
         if world > 1:

@@ -86,7 +86,27 @@ class _OracleTower:
                 g[key].copy_(g[key] + src if accumulate else src)
 
 
-def _worker(rank, world, port, out):
+class _FlatGradAdamW(torch.optim.AdamW):
+    """torch's AdamW with the gradient layout of neat_amd.optim.AdamW (which needs a GPU): every .grad is a view of
+    ``grad_buf[:n]``, two spare floats behind -- the layout tta_step's single all-reduce relies on."""
+
+    def __init__(self, params, **kw):
+        params = list(params)
+        super().__init__(params, **kw)
+        n = sum(p.numel() for p in params)
+        self.grad_buf = torch.zeros(n + 2)
+        self.flat_grad = self.grad_buf[:n]
+        off = 0
+        for p in params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+
+
+def _worker(rank, world, port, out, B=None, flat=False):
+    B = B or globals()["B"]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -99,7 +119,7 @@ def _worker(rank, world, port, out):
         model.load_state_dict(synth.synth_state_dict(MODEL, 0))
         oc.freeze_parameters(model, False)
         params, _ = oc.collect_params(model, False)
-        opt = torch.optim.AdamW(params, lr=LR, weight_decay=WD)
+        opt = (_FlatGradAdamW if flat else torch.optim.AdamW)(params, lr=LR, weight_decay=WD)
         tower = _OracleTower(model)
         model._text_tower = lambda: tower
         # test-only stand-ins for the three kernel-backed calls
@@ -113,7 +133,7 @@ def _worker(rank, world, port, out):
         lo, hi = T._shard(B, world, rank)
         local = [x[lo:hi].contiguous() for x in toks]
         for _ in range(STEPS):
-            losses, idx, S = T.tta_step(model, opt, local, G, T1, T2, world, rank)
+            losses, idx, S = T.tta_step(model, opt, local, G, T1, T2, world, rank, global_rows=B if flat else None)
         S_all = T._all_gather_rows(S, B, world)
         torch.save(dict(losses=losses, S=S_all, idx=idx, lo=lo,
                         params={k: v.detach().clone() for k, v in model.state_dict().items() if ".ln_" in k}),
@@ -140,11 +160,15 @@ def test_shard_covers_rows_in_order():
 
 
 @pytest.mark.timeout(300)
-def test_tta_step_world2_matches_single_process_oracle(tmp_path):
+@pytest.mark.parametrize("B,flat", [(7, False), (8, True)])
+def test_tta_step_world2_matches_single_process_oracle(tmp_path, B, flat):
+    """(7, False): uneven shards 4+3 (padded all_gather), per-tensor gradient all-reduces, row count by collective.
+    (8, True): even shards (all_gather_into_tensor), ONE all-reduce over grad_buf (gradients + two loss terms), the
+    caller passes the global row count -- the path bench.py and train_one_epoch take with neat_amd.optim.AdamW."""
     from neat_amd import synth
     from oracle import neat_oracle as O
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), B, flat), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
 
