@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0             # HBM3E peak, same guide
 # FETCH_SIZE doubled as the guide prescribes for gfx950 wide streaming reads -- the LN kernels in the same
 # passes confirm the factor: ln_fwd reports 80.8 MB for a 161.5 MB read).  Keyed by (M, N, K); a launch mix
 # that was not profiled reports traffic = null.
-PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 124711.91 + 631331.20) * 1024)}
+PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 122487.47 + 552320.19) * 1024)}
 
 
 def parse():
@@ -174,6 +174,7 @@ def main():
     barrier()
     timer.events.clear()
     timer.shapes.clear()
+    timer.saved_rows.clear()
     _dbg('timed region starts')
     timer.enabled = True
     t0 = time.perf_counter()
@@ -195,7 +196,10 @@ def main():
     # pre-activation h[M,4C] and u = gelu(h)[M,4C], both bf16.  Ceilings per launch: HBM bytes / 8 TB/s vs
     # FLOPs / 2.5 PFLOP/s -- for this shape the HBM ceiling is the longer one, so it is the bound.
     avg_ms, avg_flop, nl = timer.summary()
-    avg_bytes = (sum(2.0 * m * k + 4.0 * m * n + 2.0 * n * k + 4.0 * n for m, n, k in timer.shapes) / nl) if nl else 0.0
+    # algorithmic bytes of a c_fc launch: A (bf16) + W (bf16) + bias + the activation for all M rows + the saved
+    # pre-activation for the rows that will see a backward pass (3 of the 4 caption sets: 3/4 of M)
+    avg_bytes = (sum(2.0 * m * k + 2.0 * m * n + 2.0 * r * n + 2.0 * n * k + 4.0 * n
+                     for (m, n, k), r in zip(timer.shapes, timer.saved_rows)) / nl) if nl else 0.0
     sec = avg_ms * 1e-3
     gbs = avg_bytes / sec / 1e9 if sec > 0 else 0.0
     tfs = avg_flop / sec / 1e12 if sec > 0 else 0.0

@@ -90,6 +90,11 @@ int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* Wp, const float* bias
                         const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                         void* stream);
 int neat_gemm_prefers_t256(int M, int N, int K, int epilogue);
+/* NEAT_EPI_BIAS_GELU on tile256 for a forward pass whose LAST rows have no backward pass (the `neg` captions of the TTA
+ * step, reference train_TTA.py:35: coarse alignment runs under no_grad): out1 bf16 [M,N] = QuickGELU(A Wl^T + bias) for
+ * all rows, the pre-activation out0 bf16 [out0_rows,N] only for the first out0_rows <= M rows. */
+int neat_gemm_bf16_t256_gelu_rows(const uint16_t* A, const uint16_t* Wp, const float* bias, void* out0, int out0_rows,
+                                  void* out1, int M, int N, int K, void* stream);
 
 /* ---- image preprocessing of the TTA gallery loader (reference src/data/__init__.py:14-20: torchvision
  * Resize((S,S), BICUBIC) on a PIL image -> ToTensor -> Normalize; the resize is Pillow's Image.resize, restated

@@ -427,7 +427,7 @@ __host__ __device__ constexpr bool t256_shape_ok(int N, int K) { return N % 256 
 template <int EPI>
 __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
     const bf16_t* __restrict__ A, const char* __restrict__ Wp, const float* __restrict__ bias, const float* res,
-    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K) {
+    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K, int rows0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PERM = !(EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32);   // bf16 outputs
     constexpr bool HAS_BIAS = EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU;
@@ -592,7 +592,8 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
                         const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
                         up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
                     }
-                    if (out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                    // the pre-activation is kept for the first rows0 rows only (rows without a backward pass skip it)
+                    if (out0 && m < rows0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
                     *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
                 } else {  // NEAT_EPI_GELU_BWD
                     const uint32_t hp[4] = {hq->x, hq->y, hq->z, hq->w};
@@ -752,7 +753,8 @@ __global__ void pack_weight_t256_kernel(const float* __restrict__ src, bf16_t* _
 
 template <int EPI>
 static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
-                            const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
+                            const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s,
+                            int rows0 = -1) {
     static bool attr_set = false;
     if (!attr_set) {
         int rc = check_hip(hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI>,
@@ -766,7 +768,7 @@ static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* 
     const long want = (units + 7) / 8 * 8;
     const int grid = (int)(want < cus ? want : cus);
     hipLaunchKernelGGL((gemm_tile256_kernel<EPI>), dim3(grid), dim3(T_THREADS), T_LDS, s, A,
-                       reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K);
+                       reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K, rows0 < 0 ? M : rows0);
     NEAT_LAUNCH_CHECK("neat_gemm_bf16(tile256)");
     return NEAT_OK;
 }
@@ -860,6 +862,21 @@ extern "C" int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* W, const f
         default:
             return set_error(NEAT_ERR_ARG, "neat_gemm_bf16_t256: unknown epilogue %d", epilogue);
     }
+}
+
+// c_fc of a forward pass whose LAST rows have no backward pass (the `neg` captions of the TTA step): out1 = QuickGELU(A W^T
+// + bias) for all M rows, the pre-activation out0 only for the first out0_rows rows (out0 holds out0_rows rows).  Saves a
+// quarter of the 323 MB pre-activation store of the step's largest GEMM.
+extern "C" int neat_gemm_bf16_t256_gelu_rows(const uint16_t* A, const uint16_t* W, const float* bias, void* out0,
+                                             int out0_rows, void* out1, int M, int N, int K, void* stream) {
+    NEAT_REQUIRE(A && W && bias && out1, NEAT_ERR_ARG, "neat_gemm_bf16_t256_gelu_rows: null operand");
+    NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && t256_shape_ok(N, K), NEAT_ERR_SHAPE,
+                 "neat_gemm_bf16_t256_gelu_rows: M=%d N=%d K=%d unsupported (need N %% 256 == 0, K %% 128 == 0, N <= %d)", M,
+                 N, K, T_MAXN);
+    NEAT_REQUIRE(out0_rows >= 0 && out0_rows <= M && (out0 || out0_rows == 0), NEAT_ERR_ARG,
+                 "neat_gemm_bf16_t256_gelu_rows: out0_rows=%d outside 0..M=%d (or out0 is null)", out0_rows, M);
+    return launch_gemm_t256<NEAT_EPI_BIAS_GELU>(A, W, bias, nullptr, nullptr, out0_rows ? out0 : nullptr, out1, M, N, K,
+                                                (hipStream_t)stream, out0_rows);
 }
 
 // Which of the two GEMMs a caller holding BOTH weight layouts should launch (1 = tile256).  Measured inside the

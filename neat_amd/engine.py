@@ -47,17 +47,19 @@ class Stack:
         self.blocks = [BlockWeights(b, need_bwd) for b in transformer.resblocks]
         self.heads, self.causal = heads, causal
 
-    def forward(self, x, nseq: int, L: int, save: Optional[list], cu=None):
+    def forward(self, x, nseq: int, L: int, save: Optional[list], cu=None, grad_rows=None):
         """x fp32 [rows, C] -> fp32 [rows, C] (rows = nseq*L, or cu[nseq] for a packed batch with L = longest
         sequence).  With ``save`` a list, per-layer tensors needed by ``backward`` are appended (and x buffers
-        are never overwritten)."""
+        are never overwritten).  grad_rows: only the first grad_rows rows will see a backward pass (the MLP
+        pre-activation of the other rows is not kept)."""
         for w in self.blocks:
             y, _, mu1, rs1 = ops.ln_fwd(x, w.ln1_w, w.ln1_b, save_stats=save is not None)
             qkv, _ = ops.gemm(y, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
             o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None, cu=cu)
             x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
             y, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=save is not None)
-            h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"])
+            h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"],
+                            out0_rows=grad_rows if save is not None else 0)
             x2, _ = ops.gemm(u, w.w["proj"], lib.EPI_BIAS_RES_F32, bias=w.b["proj"], res=x1)
             if save is not None:
                 save.append(dict(x0=x, mu1=mu1, rs1=rs1, qkv=qkv, lse=lse, x1=x1, mu2=mu2, rs2=rs2, h=h))
@@ -106,8 +108,9 @@ class TextTower:
         self.proj = model.text_projection.detach().contiguous()
         self.proj_t = self.proj.t().contiguous()          # frozen: transposed once for the forward tile GEMM
 
-    def forward(self, tokens, normalize: bool, save: bool, packed: bool = False):
-        """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx).
+    def forward(self, tokens, normalize: bool, save: bool, packed: bool = False, n_grad=None):
+        """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx).  n_grad: only the first n_grad sequences will be
+        passed to ``backward`` (default: all).
 
         ``packed``: run only positions 0..EOT of every sequence (rows back to back).  With the causal mask and
         EOT pooling the positions after EOT cannot reach the pooled feature, nor receive gradient from it, so
@@ -120,14 +123,15 @@ class TextTower:
             cu_host = cu.cpu()                                    # one small D2H copy: row counts size the buffers
             rows, Lmax = int(cu_host[-1]), int((cu_host[1:] - cu_host[:-1]).max())
             x = ops.embed_packed_fwd(tokens, cu, rows, self.tok, self.pos)
-            x = self.stack.forward(x, nseq, Lmax, saved, cu=cu)
+            x = self.stack.forward(x, nseq, Lmax, saved, cu=cu,
+                                   grad_rows=None if n_grad is None else int(cu_host[n_grad]))
             last = (cu[1:] - 1).contiguous()                      # absolute row of each EOT token
             feat, head = ops.pool_proj_fwd(x, last, self.lnf_w, self.lnf_b, self.proj_t, nseq, 0, normalize, save=save)
             ctx = dict(saved=saved, eot=last, head=head, feat=feat, nseq=nseq, L=Lmax, normalize=normalize, cu=cu,
                        cu_host=cu_host) if save else None
             return feat, ctx
         x = ops.embed_fwd(tokens, self.tok, self.pos)
-        x = self.stack.forward(x, nseq, L, saved)
+        x = self.stack.forward(x, nseq, L, saved, grad_rows=None if n_grad is None else n_grad * L)
         eot = ops.eot_index(tokens)
         feat, head = ops.pool_proj_fwd(x, eot, self.lnf_w, self.lnf_b, self.proj_t, nseq, L, normalize, save=save)
         ctx = dict(saved=saved, eot=eot, head=head, feat=feat, nseq=nseq, L=L, normalize=normalize, cu=None) if save else None

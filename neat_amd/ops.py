@@ -28,12 +28,13 @@ class KernelTimer:
         self.epilogue = epilogue
         self.events = []
         self.shapes = []
+        self.saved_rows = []            # rows of the launch whose pre-activation was stored (BIAS_GELU: <= M)
         self.enabled = False
 
     def match(self, kind, epilogue, M, N, K):
         return self.enabled and kind == "gemm" and epilogue == self.epilogue
 
-    def region(self, M, N, K):
+    def region(self, M, N, K, saved_rows=None):
         timer = self
 
         class _R:
@@ -46,6 +47,7 @@ class KernelTimer:
                 self_r.b.record(torch.cuda.current_stream())
                 timer.events.append((self_r.a, self_r.b))
                 timer.shapes.append((M, N, K))
+                timer.saved_rows.append(M if saved_rows is None else saved_rows)
         return _R()
 
     def summary(self):
@@ -173,14 +175,33 @@ def pack_weight(w, transposed=False) -> PackedWeight:
     return PackedWeight(dst, N, K, dst256)
 
 
-def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None, out1=None, kernel=None):
+def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None, out1=None, kernel=None, out0_rows=None):
     """out[M,N] = epilogue(A[M,K] @ Wl[N,K]^T); allocates outputs that are not passed in.
-    kernel: None = the library's choice (neat_gemm_prefers_t256), "panel" / "t256" = that kernel (tests, timing)."""
+    kernel: None = the library's choice (neat_gemm_prefers_t256), "panel" / "t256" = that kernel (tests, timing).
+    out0_rows (EPI_BIAS_GELU only): the pre-activation is needed for the first out0_rows rows only; where the tile256
+    kernel runs, out0 comes back as [out0_rows, N] and the other rows are never stored."""
     M, K = A.shape
     N = W.N
     if W.K != K:
         raise RuntimeError(f"gemm: K mismatch {tuple(A.shape)} x packed [{W.N},{W.K}]")
     dev = A.device
+    force = kernel or _GEMM_FORCE
+    if (epilogue == lib.EPI_BIAS_GELU and out0_rows is not None and 0 <= out0_rows < M and out0 is None
+            and W.data256 is not None and force != "panel"
+            and (force == "t256" or lib.load().neat_gemm_prefers_t256(M, N, K, epilogue) == 1)):
+        if bias is None or bias.dtype != f32 or bias.numel() != N:
+            raise RuntimeError("gemm: BIAS_GELU needs a float32 bias of N elements")
+        out0 = torch.empty(out0_rows, N, dtype=bf16, device=dev)
+        if out1 is None:
+            out1 = torch.empty(M, N, dtype=bf16, device=dev)
+        args = (_p(A, bf16, "A"), _p(W.data256, bf16, "W"), _p(bias), _p(out0), out0_rows, _p(out1), M, N, K, _stream())
+        t = KERNEL_TIMER
+        if t is not None and t.match("gemm", epilogue, M, N, K):
+            with t.region(M, N, K, saved_rows=out0_rows):
+                lib.call("neat_gemm_bf16_t256_gelu_rows", *args)
+        else:
+            lib.call("neat_gemm_bf16_t256_gelu_rows", *args)
+        return out0, out1
     if out0 is None:
         out0 = torch.empty(M, N, dtype=f32 if epilogue in (lib.EPI_BIAS_RES_F32, lib.EPI_F32) else bf16, device=dev)
     if epilogue == lib.EPI_BIAS_GELU and out1 is None:
@@ -194,7 +215,6 @@ def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None,
         raise RuntimeError("gemm: residual shape mismatch")
     if aux is not None and (aux.dtype != bf16 or aux.shape[1] != N or aux.shape[0] < M):
         raise RuntimeError("gemm: aux shape/dtype mismatch")
-    force = kernel or _GEMM_FORCE
     if force == "t256" and kernel and W.data256 is None:
         raise RuntimeError(f"gemm: no tile256 layout for packed [{W.N},{W.K}] (need N % 256 == 0, K % 128 == 0)")
     use256 = W.data256 is not None and force != "panel" and (

@@ -92,7 +92,7 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
     Bl = text.shape[0]
     tower = model._text_tower()
     feats, ctx = tower.forward(torch.cat([text, pos, inv, neg], dim=0), True, True,
-                               packed=bool(getattr(model, "pack_tokens", False)))
+                               packed=bool(getattr(model, "pack_tokens", False)), n_grad=3 * Bl)     # neg: no backward
     t, p, v, n = feats[:Bl], feats[Bl:2 * Bl], feats[2 * Bl:3 * Bl], feats[3 * Bl:]
     coarse, idx, S = ops.coarse_align(t, p, n, gallery)
     if world > 1 or FORCE_COLLECTIVES:

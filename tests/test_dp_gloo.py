@@ -68,7 +68,7 @@ class _OracleTower:
     def _sd(self):
         return {k: v.detach() for k, v in self.model.state_dict().items()}
 
-    def forward(self, tokens, normalize, save, packed=False):
+    def forward(self, tokens, normalize, save, packed=False, n_grad=None):
         from oracle import neat_oracle as O
         feat, cache = O.encode_text_fwd(self._sd(), tokens, normalize, save=save)
         return feat, cache

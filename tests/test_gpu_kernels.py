@@ -184,6 +184,31 @@ def test_gemm_exact_at_full_size(M, N, K, kern):
         assert torch.equal(o.float(), (ref * 0.5))     # QuickGELU'(0) = 0.5
 
 
+@pytest.mark.parametrize("M,N,K,rows", [(78848, 2048, 512, 59136), (20000, 1024, 256, 12345), (20000, 1024, 256, 0)])
+def test_gemm_gelu_saves_first_rows_only(M, N, K, rows):
+    """neat_gemm_bf16_t256_gelu_rows (c_fc of a forward whose last rows have no backward): the activation equals the
+    full call bit for bit, the pre-activation equals its first `rows` rows, and no byte behind them is written."""
+    A = bf(torch.randn(M, K, generator=g(21))).to(DEV)
+    W = ops.pack_weight((torch.randn(N, K, generator=g(22)) * K ** -0.5).to(DEV))
+    bias = (torch.randn(N, generator=g(23)) * 0.1).to(DEV)
+    h_full, u_full = ops.gemm(A, W, lib.EPI_BIAS_GELU, bias=bias, kernel="t256")
+    h, u = ops.gemm(A, W, lib.EPI_BIAS_GELU, bias=bias, kernel="t256", out0_rows=rows)
+    assert tuple(h.shape) == (rows, N) and torch.equal(u, u_full) and torch.equal(h, h_full[:rows])
+    # straight through the C ABI into a larger buffer: rows behind out0_rows keep their sentinel
+    buf = torch.full((rows + 300, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    u2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    lib.call("neat_gemm_bf16_t256_gelu_rows", A.data_ptr(), W.data256.data_ptr(), bias.data_ptr(), buf.data_ptr(), rows,
+             u2.data_ptr(), M, N, K, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(buf[:rows], h_full[:rows]) and bool((buf[rows:] == 7.0).all()) and torch.equal(u2, u_full)
+    with pytest.raises(RuntimeError, match="out0_rows"):
+        lib.call("neat_gemm_bf16_t256_gelu_rows", A.data_ptr(), W.data256.data_ptr(), bias.data_ptr(), buf.data_ptr(), M + 1,
+                 u2.data_ptr(), M, N, K, torch.cuda.current_stream().cuda_stream)
+    # where the panel kernel runs, the whole pre-activation comes back (callers read the first rows only)
+    hp, up = ops.gemm(A, W, lib.EPI_BIAS_GELU, bias=bias, kernel="panel", out0_rows=rows)
+    hp_full, _ = ops.gemm(A, W, lib.EPI_BIAS_GELU, bias=bias, kernel="panel")
+    assert tuple(hp.shape) == (M, N) and torch.equal(hp, hp_full)
+
+
 def test_gemm_rejects_bad_shapes():
     A = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
     W = ops.pack_weight(torch.zeros(16, 96, device=DEV))
