@@ -18,6 +18,7 @@ import os
 import re as _re
 from typing import List, Optional, Union
 
+import numpy as np
 import torch
 
 DEFAULT_CONTEXT_LENGTH = 77
@@ -61,13 +62,18 @@ def byte_symbols() -> List[str]:
     return out
 
 
+try:                                    # looked up ONCE: a failing import inside the per-caption path costs ~0.1 ms each
+    import ftfy as _ftfy
+except ImportError:
+    _ftfy = None
+
+
 def _clean_lower(text: str) -> str:
-    try:
-        import ftfy
-        text = ftfy.fix_text(text)
-    except ImportError:
-        pass
-    text = html.unescape(html.unescape(text)).strip()
+    if _ftfy is not None:
+        text = _ftfy.fix_text(text)
+    if "&" in text:                     # html.unescape only ever changes text that holds an entity
+        text = html.unescape(html.unescape(text))
+    text = text.strip()
     return _re.sub(r"\s+", " ", text).strip().lower()
 
 
@@ -98,6 +104,7 @@ class SimpleTokenizer:
         self.sot_token_id, self.eot_token_id = self.all_special_ids[0], self.all_special_ids[1]
         self.context_length = context_length
         self._cache = {}
+        self._ids = {}                  # pre-token (as matched by the regex) -> list of vocabulary ids
 
     def _merge(self, token: str) -> List[str]:
         """Greedy BPE of one pre-token (already in byte symbols): repeatedly fuse every occurrence of the adjacent
@@ -132,9 +139,13 @@ class SimpleTokenizer:
 
     def encode(self, text: str) -> List[int]:
         ids = []
+        known = self._ids
         for tok in self.pat.findall(_clean_lower(text)):
-            tok = "".join(self.sym[b] for b in tok.encode("utf-8"))
-            ids.extend(self.encoder[p] for p in self._merge(tok))
+            hit = known.get(tok)
+            if hit is None:
+                sym = "".join(self.sym[b] for b in tok.encode("utf-8"))
+                hit = known[tok] = [self.encoder[p] for p in self._merge(sym)]
+            ids.extend(hit)
         return ids
 
     def decode(self, tokens) -> str:
@@ -148,14 +159,14 @@ class SimpleTokenizer:
         n = context_length or self.context_length
         if not n:
             raise ValueError("SimpleTokenizer: context_length must be set")
-        out = torch.zeros(len(texts), n, dtype=torch.long)
+        out = np.zeros((len(texts), n), dtype=np.int64)          # one array, filled row by row: no per-caption tensors
         for i, text in enumerate(texts):
             ids = [self.sot_token_id] + self.encode(text) + [self.eot_token_id]
             if len(ids) > n:
                 ids = ids[:n]
                 ids[-1] = self.eot_token_id
-            out[i, :len(ids)] = torch.tensor(ids)
-        return out
+            out[i, :len(ids)] = ids
+        return torch.from_numpy(out)
 
 
 def get_tokenizer(model_name: str = "", context_length: Optional[int] = None, **kwargs):

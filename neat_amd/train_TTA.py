@@ -154,17 +154,53 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
             image = image.to(device, non_blocking=True)
             all_image_embeds[index.to(device)] = model.encode_image(image, normalize=True)
     T1, T2 = args.tta_temperature, args.tta_temperature2
+    # The host never waits for the batch it has just enqueued: the four token sets go to the device as ONE pinned,
+    # non-blocking copy (a pageable copy is ordered behind the previous batch's kernels and blocks the host until they
+    # are done), and a batch's losses are logged after the NEXT batch has been enqueued (same lines, same order as the
+    # reference's per-batch `.item()` at train_TTA.py:148).  Tokenising batch i+1 then runs under the GPU time of batch i.
+    def _h2d(x):
+        if x.is_cuda:
+            return x.to(device)
+        return x.pin_memory().to(device, non_blocking=True)
+
+    def _snapshot(losses):
+        """Start the device-to-host copy of a batch's losses right behind that batch's kernels (pinned, non-blocking)
+        and mark it with an event: reading it later waits for THAT batch only.  (A plain ``.tolist()`` one batch later
+        would be ordered behind the batch enqueued in between.)"""
+        if not losses.is_cuda:
+            return losses, None
+        host = torch.empty(losses.shape, dtype=losses.dtype, pin_memory=True)
+        host.copy_(losses, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return host, done
+
+    def _log(snap):
+        host, done = snap
+        if done is not None:
+            done.synchronize()
+        le, ls, lt = host.tolist()
+        logging.info(f"\tloss_entropy: {le:.3f}, loss_sr: {ls:.3f}, loss_tri: {lt:.3f}")
+
+    pending = None
     for text, pos_text, neg_text, inv_text, idx in data_loader_text:
-        toks = [tokenizer(x).to(device) for x in (text, pos_text, neg_text, inv_text)]
+        toks = [tokenizer(x) for x in (text, pos_text, neg_text, inv_text)]
         toks = [x if x.dtype == torch.int64 else x.long() for x in toks]
+        if all(not x.is_cuda for x in toks) and len({tuple(x.shape) for x in toks}) == 1:
+            toks = list(_h2d(torch.stack(toks)).unbind(0))
+        else:
+            toks = [_h2d(x) for x in toks]
         Bt = toks[0].shape[0]
         lo, hi = _shard(Bt, world, rank)
         local = [x[lo:hi].contiguous() for x in toks]
         for _ in range(args.tta_steps):
             losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt)
-        le, ls, lt = losses.tolist()
-        logging.info(f"\tloss_entropy: {le:.3f}, loss_sr: {ls:.3f}, loss_tri: {lt:.3f}")
         if world > 1:
             sims = _all_gather_rows(sims, Bt, world)
-        score_matrix_t2i[idx.to(device)] = sims
+        score_matrix_t2i[_h2d(idx)] = sims
+        if pending is not None:
+            _log(pending)
+        pending = _snapshot(losses)
+    if pending is not None:
+        _log(pending)
     return score_matrix_i2t, score_matrix_t2i
