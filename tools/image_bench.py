@@ -46,3 +46,17 @@ us = e0.elapsed_time(e1) * 1e3 / n
 alg = sum(3 * h * w for h, w in [sizes[i % 8] for i in range(256)]) + 256 * 12 * 224 * 224
 print(f"batch of 256 mixed COCO sizes -> 224: {us:8.1f} us per batch = {us/256:6.2f} us/image, {256/us*1e6:9.0f} img/s, "
       f"{alg/us/1e3:7.1f} GB/s algorithmic")
+
+# ---- video frames (MSR-VTT shape): a loader batch of 64 clips x 4 frames, 240 x 320 -> 224, one call ----
+fr = torch.randint(0, 256, (256, 240, 320, 3), dtype=torch.uint8, device=dev)
+for _ in range(3):
+    ops.frames_preprocess(fr, 224)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    ops.frames_preprocess(fr, 224)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+byts = 256 * (240 * 320 * 3 + 3 * 224 * 224 * 4)
+print(f"256 frames 240x320 -> 224 (float antialiased bicubic): {dt * 1e6:.1f} us per call = {dt / 256 * 1e6:.2f} us/frame, "
+      f"{256 / dt:.0f} frames/s, {byts / dt / 1e9:.1f} GB/s algorithmic")
