@@ -159,7 +159,7 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     # are done), and a batch's losses are logged after the NEXT batch has been enqueued (same lines, same order as the
     # reference's per-batch `.item()` at train_TTA.py:148).  Tokenising batch i+1 then runs under the GPU time of batch i.
     def _h2d(x):
-        if x.is_cuda:
+        if x.is_cuda or torch.device(device).type != "cuda":
             return x.to(device)
         return x.pin_memory().to(device, non_blocking=True)
 
