@@ -189,6 +189,16 @@ long neat_coarse_ws_floats(int B, int N);
 int neat_coarse_align(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
                       int32_t* idx_out, float* coarse_out, float* ws, int B, int N, int D, void* stream);
 
+/* The same computation with NO workspace argument and NO allocation of any kind (no hipMalloc / hipFree, no allocating
+ * library call).  It has no counterpart in the reference: it exists for callers that cannot allocate -- code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-tile partial results live in a 2-MiB
+ * file-scope device array that every GPU the library runs on holds until the process ends.  Limit:
+ * B * ceil(N / 64) <= neat_coarse_static_max_slots() (= 262 144, e.g. B = 2048 with N = 8192); larger problems return
+ * NEAT_ERR_SHAPE.  All calls on one GPU share that array: calls that overlap on one GPU (different streams) race. */
+long neat_coarse_static_max_slots(void);
+int neat_coarse_align_static(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
+                             int32_t* idx_out, float* coarse_out, int B, int N, int D, void* stream);
+
 /* ---- TTA loss forward + gradient, train_TTA.py:138-143 with :45-48, :53-65, :77-91 ---- */
 /* text,pos,inv f32 [Bl,D] are this rank's rows [row0,row0+Bl) of the global batch; text_all/coarse_all
  * f32 [B,D] are all B rows (== text/coarse when single-GPU).  losses f32 [3]: [0] = entropy term of the

@@ -319,6 +319,50 @@ extern "C" int neat_coarse_align(const float* q, const float* pos, const float* 
     return NEAT_OK;
 }
 
+// ---- neat_coarse_align without a caller workspace and without any allocation (for callers that cannot allocate:
+// code under HIP graph capture, tight serving loops).  The per-tile (max, argmax) partials live in a file-scope device
+// array; every GPU the library runs on holds its own copy at its own address, looked up once per device.
+constexpr long COARSE_STATIC_SLOTS = 1L << 18;               // B * ceil(N / 64) <= 262 144 (e.g. B = 2048, N = 8192)
+static __device__ __align__(256) float scratch[2 * COARSE_STATIC_SLOTS];   // 2 MiB per GPU, held until the process ends
+constexpr int MAX_DEVICES = 64;
+static float* g_scratch_ptr[MAX_DEVICES] = {};               // device address of `scratch` per device (NOT the symbol)
+
+static int coarse_scratch(float** out) {
+    int dev = -1;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    NEAT_REQUIRE(dev >= 0 && dev < MAX_DEVICES, NEAT_ERR_ARG, "neat_coarse_align_static: device %d out of range", dev);
+    float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        // once per device, with that device current; racing first calls look up the same address
+        rc = check_hip(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+        if (rc) return rc;
+        NEAT_REQUIRE(p != nullptr, NEAT_ERR_HIP, "neat_coarse_align_static: null scratch address on device %d", dev);
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return NEAT_OK;
+}
+
+extern "C" long neat_coarse_static_max_slots(void) { return COARSE_STATIC_SLOTS; }
+
+extern "C" int neat_coarse_align_static(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
+                                        int32_t* idx_out, float* coarse_out, int B, int N, int D, void* stream) {
+    NEAT_REQUIRE(q && pos && neg && G && S_out && idx_out && coarse_out, NEAT_ERR_ARG,
+                 "neat_coarse_align_static: null pointer");
+    NEAT_REQUIRE(B > 0 && N > 0 && D > 0 && D % SG_K == 0, NEAT_ERR_SHAPE,
+                 "neat_coarse_align_static: D=%d must be a multiple of 16", D);
+    const long slots = (long)B * cdiv(N, SG_T);
+    NEAT_REQUIRE(slots <= COARSE_STATIC_SLOTS, NEAT_ERR_SHAPE,
+                 "neat_coarse_align_static: B * ceil(N/64) = %ld exceeds the static scratch of %ld slots "
+                 "(use neat_coarse_align with a caller workspace)", slots, COARSE_STATIC_SLOTS);
+    float* ws = nullptr;
+    int rc = coarse_scratch(&ws);
+    if (rc) return rc;
+    // every slot the final kernel reads is written by the tile kernel of THIS call: nothing needs clearing
+    return neat_coarse_align(q, pos, neg, G, S_out, idx_out, coarse_out, ws, B, N, D, stream);
+}
+
 extern "C" long neat_loss_ws_floats(int B, int Bl) { return (long)B * B + (long)Bl * B + B + 3L * Bl; }
 
 extern "C" int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const float* inv, const float* text_all,

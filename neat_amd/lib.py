@@ -48,6 +48,8 @@ SIGNATURES = {
     "neat_frame_mean_norm": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_coarse_ws_floats": (_L, [_I, _I]),
     "neat_coarse_align": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "neat_coarse_static_max_slots": (_L, []),
+    "neat_coarse_align_static": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "neat_loss_ws_floats": (_L, [_I, _I]),
     "neat_tta_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_adamw_flat": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _I, _P]),

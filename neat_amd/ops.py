@@ -424,6 +424,18 @@ def coarse_align(q, pos, neg, G):
     return coarse, idx, S
 
 
+def coarse_align_static(q, pos, neg, G, S, idx, coarse):
+    """neat_coarse_align_static: the caller passes every output; the call allocates nothing (the per-tile partials live
+    in the library's static device array; B * ceil(N/64) <= neat_coarse_static_max_slots())."""
+    B, D = q.shape
+    N = G.shape[0]
+    if tuple(S.shape) != (B, N) or tuple(idx.shape) != (B,) or tuple(coarse.shape) != (B, D):
+        raise RuntimeError("coarse_align_static: output shapes must be S [B,N], idx [B], coarse [B,D]")
+    lib.call("neat_coarse_align_static", _p(q, f32, "q"), _p(pos, f32, "pos"), _p(neg, f32, "neg"), _p(G, f32, "G"),
+             _p(S, f32, "S"), _p(idx, i32, "idx"), _p(coarse, f32, "coarse"), B, N, D, _stream())
+    return coarse, idx, S
+
+
 def tta_loss_fwd_bwd(text, pos, inv, text_all, coarse_all, T1, T2, row0=0):
     Bl, D = text.shape
     B = text_all.shape[0]
