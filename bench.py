@@ -15,7 +15,7 @@ N>1 (launched by torch.distributed.run): weak scaling -- every rank owns 256 row
 256*N (BASELINE config 3's sharding); features are all-gathered and LN gradients all-reduced over RCCL.
 
 Extra objects on the JSON line: ``roofline`` for the dominant kernel (c_fc bf16 MFMA GEMM + fused GELU, timed with HIP events
-on its stream inside the timed region) and ``cpu_baseline`` (the CPU oracle on a bounded sample of the same
+on its stream inside the timed region; FLOP/s against the dense bf16 MFMA peak, the HBM figure beside it) and ``cpu_baseline`` (the CPU oracle on a bounded sample of the same
 workload, rank 0, N=1 only).
 """
 import argparse
@@ -210,13 +210,18 @@ def main():
     t256 = bool(shapes) and lib.load().neat_gemm_prefers_t256(*shape0, lib.EPI_BIAS_GELU) == 1
     if not t256:
         traffic = None                                             # the PMC passes profiled the tile256 launch
-    roofline = dict(bound="hbm", kernel=("gemm_tile256_kernel" if t256 else "gemm_panel_kernel") +
+    # SURVEY.md §8(d) classes the encoder GEMMs as MFMA rows: the headline fraction is FLOP/s against the dense bf16
+    # MFMA peak.  The same launch against the HBM roof (its algorithmic bytes / 8 TB/s is the LONGER of its two
+    # ceilings: 255 FLOP/B against a ridge of 312) is given beside it as hbm_*.
+    roofline = dict(bound="mfma", kernel=("gemm_tile256_kernel" if t256 else "gemm_panel_kernel") +
                     "<NEAT_EPI_BIAS_GELU> (c_fc: M=4*B*77, N=4C, K=C)",
-                    achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                    achieved=round(tfs, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tfs / MFMA_BF16_PEAK_TFLOPS, 4),
                     traffic=traffic, launches=nl, avg_launch_ms=round(avg_ms, 4),
-                    algorithmic_bytes_per_launch=int(avg_bytes), mfma_tflops=round(tfs, 1),
-                    mfma_frac=round(tfs / MFMA_BF16_PEAK_TFLOPS, 4),
-                    step_tflops=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12, 1))
+                    algorithmic_flop_per_launch=int(avg_flop), algorithmic_bytes_per_launch=int(avg_bytes),
+                    hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+                    step_tflops=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12, 1),
+                    step_mfma_frac=round(pairs / world * a.tta_steps * flops_row_step / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
 
     # ---- extra, NOT the headline: the same batches with the opt-in packed text batches (positions after EOT
     # dropped; identical outputs, tests/test_gpu_tta.py::test_packed_tokens_equal_full_length) ----
@@ -274,7 +279,11 @@ def cpu_baseline(a, cfg):
     (gallery encode excluded, as in the GPU number)."""
     from neat_amd import synth
     from oracle import neat_oracle as O
-    cores = min(16, os.cpu_count() or 1)
+    # every core this process may use: its affinity mask, bounded by OMP_NUM_THREADS where the box sets a CPU share
+    # (os.cpu_count() reports the whole machine there, many times this job's share)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = min(avail, share) if share > 0 else avail
     torch.set_num_threads(cores)
     sd = synth.synth_state_dict(a.model, 0)
     t = cfg["text_cfg"]
@@ -286,7 +295,7 @@ def cpu_baseline(a, cfg):
     for _ in range(a.tta_steps):
         losses_c, idx_c, S_c = O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)[:3]
     dt = time.perf_counter() - t0
-    out = dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, kind="port",
+    out = dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, cores_visible=avail, kind="port",
                sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, {a.model}, fp32 torch CPU oracle, "
                       f"{dt:.1f} s")
     # the same sample through the HIP path: recall@1 of both legs on the produced score rows (synthetic ground
@@ -307,7 +316,14 @@ def cpu_baseline(a, cfg):
                               cpu=round(float((S_c.argmax(1) == truth).float().mean()), 4),
                               top1_agreement=round(float((S_g.argmax(1) == S_c.argmax(1)).float().mean()), 4),
                               loss_rel_diff=round(float(abs(losses_g.sum().item() - float(sum(losses_c))) /
-                                                        abs(float(sum(losses_c)))), 6))
+                                                        abs(float(sum(losses_c)))), 6),
+                              # per term (entropy, semantics reversion, triplet): the hinge-max SR term moves when a
+                              # coarse index flips under bf16 features; the other two stay within ~1e-4
+                              loss_terms_gpu=[round(float(x), 6) for x in losses_g.tolist()],
+                              loss_terms_cpu=[round(float(x), 6) for x in losses_c],
+                              loss_term_rel_diff=[round(abs(float(g_) - float(c_)) / max(abs(float(c_)), 1e-12), 6)
+                                                  for g_, c_ in zip(losses_g.tolist(), losses_c)],
+                              coarse_idx_mismatch=int((idx_g.cpu().long() != idx_c).sum()))
     return out
 
 

@@ -503,13 +503,8 @@ template <int NT>
 static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
                       hipStream_t s) {
     constexpr size_t lds = (size_t)AT_WAVES * HD * (NT * 16 + 8) * 2;
-    static bool attr = false;
-    if (!attr) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attn_fwd attr");
-        if (rc) return rc;
-        attr = true;
-    }
+    static unsigned long long attr_done = 0;                    // per template instance, one bit per device
+    if (int rc = ensure_dynamic_lds((const void*)attn_fwd_kernel<NT>, (int)lds, &attr_done, "attn_fwd attr")) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(cdiv((long)nseq * heads, AT_WAVES)), dim3(AT_THREADS), lds, s, qkv,
                        out, lse, nseq, L, heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_fwd");
@@ -530,13 +525,8 @@ template <int NT>
 static int launch_bwd(const uint16_t* qkv, const uint16_t* dout, const float* lse, uint16_t* dqkv, const int32_t* cu,
                       int nseq, int L, int heads, int causal, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * NT * 16 * AB_PITCH * 2 + 2 * NT * 16 * 4 + (size_t)AB_WAVES * 16 * AB_PITCH * 2;
-    static bool attr = false;
-    if (!attr) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)attn_bwd_kernel<NT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attn_bwd attr");
-        if (rc) return rc;
-        attr = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_kernel<NT>, (int)lds, &attr_done, "attn_bwd attr")) return rc;
     hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, dout, lse, dqkv, cu, nseq,
                        L, heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_bwd");

@@ -21,6 +21,18 @@ int check_hip(hipError_t e, const char* what) {
     return set_error(NEAT_ERR_HIP, "%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
 }
 
+int ensure_dynamic_lds(const void* fn, int bytes, unsigned long long* done, const char* what) {
+    int dev = 0;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return NEAT_OK;
+    rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+    if (rc) return rc;
+    __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);       // racing first calls set the same attribute twice: harmless
+    return NEAT_OK;
+}
+
 }  // namespace neat
 
 extern "C" const char* neat_version(void) { return "neat_hip 0.1 (gfx950)"; }

@@ -75,6 +75,10 @@ int check_hip(hipError_t e, const char* what);
 // loss.hip: C[M,N] = A[M,K] . B[N,K]^T, exact fp32 FMA chains in k order; K % 16 == 0
 int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per device (bit d of `done`),
+// not per process.  Call before launching `fn` with more than 64 KiB of dynamic LDS.
+int ensure_dynamic_lds(const void* fn, int bytes, unsigned long long* done, const char* what);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace neat

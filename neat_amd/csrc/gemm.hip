@@ -348,14 +348,10 @@ template <int EPI, int BKH, int NI, int OCC>
 static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                          const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int grid, hipStream_t s) {
     constexpr int ldsb = lds_total_bytes(BKH, NI);
-    static bool attr_set = false;  // per-template-instance: allow > 64 KiB dynamic LDS
-    if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)gemm_panel_kernel<EPI, BKH, NI, OCC>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsb),
-                           "hipFuncSetAttribute(gemm)");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;  // per template instance, one bit per device: allow > 64 KiB dynamic LDS
+    if (int rc = ensure_dynamic_lds((const void*)gemm_panel_kernel<EPI, BKH, NI, OCC>, ldsb, &attr_done,
+                                    "hipFuncSetAttribute(gemm)"))
+        return rc;
     hipLaunchKernelGGL((gemm_panel_kernel<EPI, BKH, NI, OCC>), dim3(grid), dim3(P_THREADS), ldsb, s, A,
                        reinterpret_cast<const uint4*>(Wp), bias, res, aux, out0, out1, M, N, K);
     NEAT_LAUNCH_CHECK("neat_gemm_bf16");
@@ -755,14 +751,10 @@ template <int EPI>
 static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                             const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s,
                             int rows0 = -1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS),
-                           "hipFuncSetAttribute(gemm_tile256)");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_dynamic_lds((const void*)gemm_tile256_kernel<EPI>, T_LDS, &attr_done,
+                                    "hipFuncSetAttribute(gemm_tile256)"))
+        return rc;
     const long units = (long)cdiv(M, 256) * (N / 256);
     const int cus = num_cus();
     const long want = (units + 7) / 8 * 8;

@@ -59,6 +59,15 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     if cfg is None:
         raise RuntimeError(f"Model config for {model_name} not found; available: {list_models()}")
     cfg = dict(cfg, **{k: v for k, v in model_kwargs.items() if k in ("embed_dim", "vision_cfg", "text_cfg")})
+    # The kernels implement QuickGELU (OpenAI-family weights; reference model.py:498 builds those with quick_gelu=True).
+    # Without a checkpoint the weights are random and QuickGELU is simply this model's activation.  WITH a checkpoint
+    # the activation must be the one the weights were trained with: an nn.GELU checkpoint (e.g. laion ViT-B-32) has the
+    # same state-dict keys and would load cleanly and give wrong features, so the caller has to say QuickGELU.
+    quick_gelu = bool(cfg.get("quick_gelu", False) or force_quick_gelu)
+    if pretrained and not quick_gelu:
+        raise RuntimeError(f"create_model({model_name!r}, pretrained={pretrained!r}): only QuickGELU (OpenAI-family) "
+                           f"weights are supported; pass force_quick_gelu=True (or a *-quickgelu config) if the "
+                           f"checkpoint was trained with QuickGELU")
     model = CLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)
     if pretrained:
         if os.path.exists(pretrained):

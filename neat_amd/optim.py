@@ -44,6 +44,16 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
+        # the parameters and their gradients must still be the views made in __init__: a later model.to()/.float()/
+        # .cuda() re-creates p.data, and p.grad = None drops the gradient view -- the step would then update buffers
+        # nobody reads.  Two pointer comparisons per step (first and last parameter).
+        off_last = self.flat_param.numel() - g["params"][-1].numel()
+        for p, off in ((g["params"][0], 0), (g["params"][-1], off_last)):
+            if (p.data_ptr() != self.flat_param[off:].data_ptr() or p.grad is None
+                    or p.grad.data_ptr() != self.flat_grad[off:].data_ptr()):
+                raise RuntimeError("neat_amd.optim.AdamW: a parameter (or its .grad) no longer aliases the optimizer's flat "
+                                   "buffers -- build the optimizer AFTER moving/casting the model, and clear gradients "
+                                   "with optimizer.zero_grad() rather than p.grad = None")
         self.step_count += 1
         ops.adamw_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
                        g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])

@@ -12,8 +12,11 @@ What differs from the reference, by design:
   * the gallery buffer is sized from the model's embed dim (the reference hard-codes 512, :119);
   * opt-in ``model.pack_tokens = True``: the text tower runs only positions 0..EOT of every caption (dead rows
     behind the causal mask are dropped; same features, losses and LN gradients up to fp32 summation order);
-  * data parallelism: every rank iterates the same batches, owns a contiguous row shard of
-    each, all-gathers text features + coarse image features, and all-reduces the LN gradients.
+  * data parallelism: a rank owns a contiguous row shard of every caption batch and a share of the
+    gallery; it all-gathers text features + coarse image features, sums the LN gradients of all ranks, and gathers the
+    gallery embeddings and the score rows.  Both loader wirings are accepted, per loader: ``DistributedSampler``s as the
+    reference's launcher hands them out (main_TTA.py:245-257: every rank sees its own rows, batch = tta_total_bs //
+    world), or replicated loaders (every rank iterates the same batches and cuts its shard out of each).
 """
 from __future__ import annotations
 
@@ -55,19 +58,88 @@ def _shard(n: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _host_staged(x) -> bool:
+    """gloo moves GPU tensors through the host by itself, and with several ranks on one card that path has hung on this
+    stack (ROCm 7, torch 2.10): under gloo the collectives below stage GPU tensors through host memory explicitly.  RCCL
+    ("nccl"), the backend of a real multi-GPU run, takes the device tensors as they are."""
+    return x.is_cuda and dist.get_backend() == "gloo"
+
+
+def _gather_into(out, x):
+    """dist.all_gather_into_tensor(out, x) (rank order along dim 0)."""
+    if _host_staged(x):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, x.contiguous().cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, x.contiguous())
+
+
+def _reduce_sum(x):
+    if _host_staged(x):
+        host = x.cpu()
+        dist.all_reduce(host)
+        x.copy_(host)
+    else:
+        dist.all_reduce(x)
+
+
 def _all_gather_rows(x, n_total: int, world: int):
     """Concatenate row shards of (possibly) different sizes from all ranks, in rank order."""
     sizes = [_shard(n_total, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
     if all(hi - lo == mx for lo, hi in sizes):                    # even shards: one output tensor, no padding, no cat
         out = torch.empty(world * mx, *x.shape[1:], dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous())
+        _gather_into(out, x)
         return out
     pad = torch.zeros(mx, *x.shape[1:], dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
-    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+    out = torch.empty(world * mx, *x.shape[1:], dtype=x.dtype, device=x.device)
+    _gather_into(out, pad)
+    return torch.cat([out[r * mx: r * mx + hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def _all_gather_ragged(x, world: int):
+    """Rows of every rank (any row counts, zero included) -> (list of per-rank tensors, in rank order).  One small
+    host-synchronising collective for the counts, one padded all-gather for the data: used once per epoch (gallery)."""
+    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+    counts = torch.empty(world, dtype=torch.int64, device=x.device)
+    _gather_into(counts, n)
+    counts = [int(c) for c in counts.tolist()]
+    mx = max(max(counts), 1)
+    pad = torch.zeros(mx, *x.shape[1:], dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    out = torch.empty(world * mx, *x.shape[1:], dtype=x.dtype, device=x.device)
+    _gather_into(out, pad)
+    return [out[r * mx: r * mx + c] for r, c in enumerate(counts)]
+
+
+def _distributed_sampler(loader):
+    """The DistributedSampler behind a loader (a DataLoader, or one of the GPU loaders that wrap one), or None."""
+    from torch.utils.data.distributed import DistributedSampler
+    seen = 0
+    while loader is not None and seen < 4:
+        for attr in ("sampler", "batch_sampler"):
+            smp = getattr(loader, attr, None)
+            smp = getattr(smp, "sampler", smp) if attr == "batch_sampler" else smp
+            if isinstance(smp, DistributedSampler):
+                return smp
+        loader = getattr(loader, "loader", None)
+        seen += 1
+    return None
+
+
+def _loader_is_sharded(loader, world: int, rank: int, what: str) -> bool:
+    smp = _distributed_sampler(loader)
+    if smp is None or world == 1:
+        if smp is not None and smp.num_replicas > 1:
+            raise RuntimeError(f"train_one_epoch: the {what} loader has a DistributedSampler over {smp.num_replicas} "
+                               f"replicas but args.distributed is off: rows of the other replicas would never be seen")
+        return False
+    if smp.num_replicas != world or smp.rank != rank:
+        raise RuntimeError(f"train_one_epoch: the {what} loader's DistributedSampler is (replicas {smp.num_replicas}, "
+                           f"rank {smp.rank}) but the process group is (world {world}, rank {rank})")
+    return smp.num_replicas > 1
 
 
 def _ln_grad_views(model):
@@ -98,7 +170,7 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
     if world > 1 or FORCE_COLLECTIVES:
         if global_rows is None:
             B = torch.tensor([Bl], device=t.device)
-            dist.all_reduce(B)
+            _reduce_sum(B)
             B = int(B.item())
         else:
             B = int(global_rows)
@@ -121,14 +193,14 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
             # host for 1.7 ms (tools/rccl_probe.py), which the launch-bound tail of the step cannot hide.
             buf[-2:].copy_(losses[1:])
             gathered = torch.empty(world, buf.numel(), dtype=buf.dtype, device=buf.device)
-            dist.all_gather_into_tensor(gathered.view(-1), buf)
+            _gather_into(gathered.view(-1), buf)
             torch.sum(gathered, dim=0, out=buf)
             losses[1:].copy_(buf[-2:])
         else:
             for g in grads:
                 for x in g.values():
-                    dist.all_reduce(x)
-            dist.all_reduce(losses[1:])      # sr / triplet are sums over local rows; entropy is already global
+                    _reduce_sum(x)
+            _reduce_sum(losses[1:])          # sr / triplet are sums over local rows; entropy is already global
     optimizer.step()
     optimizer.zero_grad()
     return losses, idx, S
@@ -147,12 +219,37 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     if getattr(args, "tta_only_visual", False):
         return score_matrix_i2t, score_matrix_t2i      # reference: `pass` (train_TTA.py:113-114)
 
+    # which rows does this rank see?  (raises on a sampler that does not match the process group)
+    text_sharded = _loader_is_sharded(data_loader_text, world, rank, "text")
+    image_sharded = _loader_is_sharded(data_loader_image, world, rank, "image")
+
     D = clip.text_projection.shape[1]
     all_image_embeds = torch.zeros(len_image, D, device=device)
+    # Phase A (train_TTA.py:120-124).  With W ranks every rank encodes 1/W of the gallery -- its sampler's images, or
+    # its row shard of every replicated batch -- and ONE ragged all-gather at the end replicates the embeddings.
     with torch.no_grad():
+        mine_idx, mine_emb = [], []
         for image, index in data_loader_image:
-            image = image.to(device, non_blocking=True)
-            all_image_embeds[index.to(device)] = model.encode_image(image, normalize=True)
+            if world > 1 and not image_sharded:
+                lo, hi = _shard(len(index), world, rank)
+                if hi == lo:
+                    continue
+                image, index = image[lo:hi], index[lo:hi]
+            emb = model.encode_image(image.to(device, non_blocking=True), normalize=True)
+            if world == 1:
+                all_image_embeds[index.to(device)] = emb
+            else:
+                mine_idx.append(index.to(device).view(-1))
+                mine_emb.append(emb)
+        if world > 1:
+            idx_l = torch.cat(mine_idx) if mine_idx else torch.zeros(0, dtype=torch.int64, device=device)
+            emb_l = torch.cat(mine_emb) if mine_emb else torch.zeros(0, D, device=device)
+            packed = torch.cat([emb_l, idx_l.to(emb_l.dtype).view(-1, 1)], dim=1)     # indices < 2^24: exact in fp32
+            if len_image >= (1 << 24):
+                raise RuntimeError("train_one_epoch: gallery too large for the fp32 index column of the gather")
+            # rank order, so that an image a padded sampler hands to two ranks is written the same way everywhere
+            for part in _all_gather_ragged(packed, world):
+                all_image_embeds[part[:, D].long()] = part[:, :D]
     T1, T2 = args.tta_temperature, args.tta_temperature2
     # The host never waits for the batch it has just enqueued: the four token sets go to the device as ONE pinned,
     # non-blocking copy (a pageable copy is ordered behind the previous batch's kernels and blocks the host until they
@@ -190,14 +287,26 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
             toks = list(_h2d(torch.stack(toks)).unbind(0))
         else:
             toks = [_h2d(x) for x in toks]
-        Bt = toks[0].shape[0]
-        lo, hi = _shard(Bt, world, rank)
-        local = [x[lo:hi].contiguous() for x in toks]
+        idx = _h2d(idx).view(-1)
+        if text_sharded:
+            # the sampler already cut the global batch: these ARE the local rows.  A DistributedSampler pads its index
+            # list, so every rank holds the same number of rows in every batch and rank r owns rows [r*Bl, (r+1)*Bl).
+            local, Bl = toks, toks[0].shape[0]
+            Bt = Bl * world
+            idx = _all_gather_rows(idx.view(-1, 1), Bt, world).view(-1)
+        else:
+            Bt = toks[0].shape[0]
+            if Bt < world:
+                # the same decision on every rank, before any collective: a rank with no rows would fail alone and
+                # leave the others waiting in the all-gather
+                raise RuntimeError(f"train_one_epoch: a batch of {Bt} caption rows cannot be cut over {world} ranks")
+            lo, hi = _shard(Bt, world, rank)
+            local = [x[lo:hi].contiguous() for x in toks]
         for _ in range(args.tta_steps):
             losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt)
         if world > 1:
             sims = _all_gather_rows(sims, Bt, world)
-        score_matrix_t2i[_h2d(idx)] = sims
+        score_matrix_t2i[idx] = sims
         if pending is not None:
             _log(pending)
         pending = _snapshot(losses)

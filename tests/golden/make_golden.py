@@ -114,8 +114,25 @@ def make_batches(cfg, n_text, n_image, bs_text, bs_image, data_seed):
     return tb, ib
 
 
+class _TorchWithGalleryWidth:
+    """``torch`` as train_TTA sees it, with ONE change: the gallery buffer the reference hard-codes to 512 columns
+    (train_TTA.py:119) is made ``width`` columns wide, so that a D = 768 model (ViT-L-14) can run at all
+    (SURVEY.md §0).  Everything else is forwarded to torch untouched."""
+
+    def __init__(self, width):
+        self._w = width
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def zeros(self, *size, **kw):
+        if len(size) == 2 and size[1] == 512:
+            size = (size[0], self._w)
+        return torch.zeros(*size, **kw)
+
+
 def run_instrumented(oc, tt, model, tb, ib, n_text, n_image, steps=3, lr=2e-4, wd=1e-3, T1=0.03, T2=0.07,
-                     keep_rows=8):
+                     keep_rows=8, gallery_width=None):
     """Unmodified train_one_epoch with capture hooks."""
     oc.freeze_parameters(model, False)
     params, names = oc.collect_params(model, False)
@@ -160,6 +177,9 @@ def run_instrumented(oc, tt, model, tb, ib, n_text, n_image, steps=3, lr=2e-4, w
 
     tt.coarse_aligning_t2i, tt.softmax_entropy, tt.semantics_reversion_loss, tt.textual_triplet_loss = \
         coarse, ent, sr, tri
+    o_torch = tt.torch
+    if gallery_width is not None and gallery_width != 512:
+        tt.torch = _TorchWithGalleryWidth(gallery_width)
     try:
         opt = Opt(params, lr=lr, weight_decay=wd)       # main_TTA.py:271
         args = types.SimpleNamespace(distributed=False, tta_only_visual=False, name="neat", tta_steps=steps,
@@ -169,6 +189,7 @@ def run_instrumented(oc, tt, model, tb, ib, n_text, n_image, steps=3, lr=2e-4, w
                                       FakeLoader(ib, n_image, "image"), opt, torch.device("cpu"), args)
         rec["seconds"] = time.time() - t0
     finally:
+        tt.torch = o_torch
         tt.coarse_aligning_t2i, tt.softmax_entropy, tt.semantics_reversion_loss, tt.textual_triplet_loss = \
             o_coarse, o_ent, o_sr, o_tri
     rec["score"] = score
@@ -191,7 +212,7 @@ def case_tta(oc, tt, retrieval, tag, model_name, n_text, n_image, bs_text, bs_im
     with torch.no_grad():
         img_rows = model.encode_image(ib[0][0][:8], normalize=True).clone()
         txt_unnorm = model.encode_text(tb[0][0][:8], normalize=False).clone()
-    rec = run_instrumented(oc, tt, model, tb, ib, n_text, n_image)
+    rec = run_instrumented(oc, tt, model, tb, ib, n_text, n_image, gallery_width=cfg["embed_dim"])
     out = dict(
         meta=np.array(json.dumps(dict(model=model_name, n_text=n_text, n_image=n_image, bs_text=bs_text,
                                       bs_image=bs_image, wseed=wseed, dseed=dseed, steps=3, lr=2e-4, wd=1e-3,
@@ -309,6 +330,11 @@ def main():
         elif c == "vitb32_b256":
             case_tta(oc, tt, retrieval, "vitb32_b256", "ViT-B-32", n_text=256, n_image=256, bs_text=256,
                      bs_image=64, store_score=False, store_grads=True)
+        elif c == "vitl14_b128":
+            # config 3's model (ViT-L-14: text width 768, D = 768) at a batch the reference's autograd fits in this
+            # container's memory; the only change to the reference is the gallery-buffer width (see above)
+            case_tta(oc, tt, retrieval, "vitl14_b128", "ViT-L-14", n_text=128, n_image=32, bs_text=128,
+                     bs_image=8, store_score=False, store_grads=True)
         else:
             raise SystemExit(f"unknown case {c}")
 

@@ -192,3 +192,175 @@ def test_tta_step_world2_matches_single_process_oracle(tmp_path, B, flat):
         assert torch.equal(r0["params"][k], r1["params"][k]), k
     assert torch.equal(torch.cat([r0["idx"], r1["idx"]]), idx)
     assert (r0["lo"], r1["lo"]) == (0, 4)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# train_one_epoch under both loader wirings: DistributedSamplers as the reference's
+# launcher hands them out (main_TTA.py:245-257, through the package's own create_sampler / create_loader), and replicated
+# loaders that every rank iterates in full.  Same CPU stand-ins for the kernel-backed calls as above.
+N_TEXT, N_IMG, BS_LOCAL, BS_IMG = 13, 9, 4, 4        # 13 -> padded to 14 rows (7 per rank: batches of 4 + 3); 9 -> 10 images
+
+
+class _TextDS(torch.utils.data.Dataset):
+    def __init__(self, sets):
+        self.sets = sets
+        self.text = list(range(sets[0].shape[0]))
+
+    def __len__(self):
+        return len(self.text)
+
+    def __getitem__(self, i):
+        return tuple(s[i] for s in self.sets) + (i,)
+
+
+class _ImageDS(torch.utils.data.Dataset):
+    def __init__(self, images):
+        self.images = images
+        self.image = list(range(images.shape[0]))
+
+    def __len__(self):
+        return len(self.image)
+
+    def __getitem__(self, i):
+        return self.images[i], i
+
+
+class _ListLoader:
+    def __init__(self, batches, n, attr):
+        self.batches = batches
+        self.dataset = type("DS", (), {})()
+        setattr(self.dataset, attr, list(range(n)))
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def _epoch_inputs():
+    from neat_amd import synth
+    cfg = synth.get_cfg(MODEL)
+    t = cfg["text_cfg"]
+    sets = synth.synth_caption_sets(N_TEXT, t["context_length"], t["vocab_size"], 99)
+    images = synth.synth_images(N_IMG, cfg["vision_cfg"]["image_size"], 98)
+    return sets, images
+
+
+def _sampler_order(n, world):
+    """Index lists a DistributedSampler(shuffle=False, drop_last=False) hands to each rank."""
+    total = (n + world - 1) // world * world
+    order = list(range(n)) + list(range(total - n))
+    return [order[r::world] for r in range(world)]
+
+
+def _epoch_worker(rank, world, port, out, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from neat_amd import open_clip as oc, ops
+        from neat_amd import train_TTA as T
+        from neat_amd.data import create_loader, create_sampler
+        from neat_amd import synth
+        from oracle import neat_oracle as O
+
+        model = oc.create_model(MODEL, device="cpu")
+        model.load_state_dict(synth.synth_state_dict(MODEL, 0))
+        oc.freeze_parameters(model, False)
+        params, _ = oc.collect_params(model, False)
+        opt = _FlatGradAdamW(params, lr=LR, weight_decay=WD)
+        tower = _OracleTower(model)
+        model._text_tower = lambda: tower
+        model.encode_image = lambda image, normalize=True: O.encode_image_fwd(tower._sd(), image, normalize)
+        ops.coarse_align = lambda t, p, n, G: O.coarse_align_t2i(t, p, n, G)
+        ops.tta_loss_fwd_bwd = _sharded_loss_cpu
+        sets, images = _epoch_inputs()
+        args = types.SimpleNamespace(distributed=True, tta_only_visual=False, name="neat", tta_steps=STEPS,
+                                     tta_temperature=T1, tta_temperature2=T2)
+        if mode == "sampler":
+            ds = [_TextDS(sets), _ImageDS(images)]
+            samplers = create_sampler(ds, [False, False], world, rank)
+            lt, li = create_loader(ds, samplers, batch_size=[BS_LOCAL, BS_IMG], num_workers=[0, 0],
+                                   is_trains=[False, False], collate_fns=[None, None])
+        elif mode == "replicated":
+            tb = [tuple(x[i:i + 2 * BS_LOCAL] for x in sets) + (torch.arange(N_TEXT)[i:i + 2 * BS_LOCAL],)
+                  for i in range(0, N_TEXT, 2 * BS_LOCAL)]
+            ib = [(images[i:i + BS_IMG], torch.arange(N_IMG)[i:i + BS_IMG]) for i in range(0, N_IMG, BS_IMG)]
+            lt, li = _ListLoader(tb, N_TEXT, "text"), _ListLoader(ib, N_IMG, "image")
+        elif mode == "mismatch":
+            ds = [_TextDS(sets), _ImageDS(images)]
+            samplers = create_sampler(ds, [False, False], world + 1, rank)      # sampler over 3 replicas, group of 2
+            lt, li = create_loader(ds, samplers, batch_size=[BS_LOCAL, BS_IMG], num_workers=[0, 0],
+                                   is_trains=[False, False], collate_fns=[None, None])
+        else:                                                                    # "tiny_batch": 1 row for 2 ranks
+            tb = [tuple(x[:1] for x in sets) + (torch.arange(1),)]
+            ib = [(images, torch.arange(N_IMG))]
+            lt, li = _ListLoader(tb, N_TEXT, "text"), _ListLoader(ib, N_IMG, "image")
+        err = None
+        try:
+            _, score = T.train_one_epoch(model, lambda x: x, lt, li, opt, torch.device("cpu"), args)
+        except RuntimeError as e:
+            err, score = str(e), None
+        torch.save(dict(score=score, err=err,
+                        params={k: v.detach().clone() for k, v in model.state_dict().items() if ".ln_" in k}),
+                   os.path.join(out, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["sampler", "replicated"])
+def test_train_one_epoch_world2_equals_single_process_oracle(tmp_path, mode):
+    from neat_amd import synth
+    from oracle import neat_oracle as O
+
+    mp.spawn(_epoch_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert r0["err"] is None and r1["err"] is None, (r0["err"], r1["err"])
+
+    sets, images = _epoch_inputs()
+    if mode == "sampler":
+        per_rank = _sampler_order(N_TEXT, 2)
+        n_local = len(per_rank[0])
+        batches_idx = [sum((pr[k:k + BS_LOCAL] for pr in per_rank), []) for k in range(0, n_local, BS_LOCAL)]
+        assert [len(b) for b in batches_idx] == [8, 6] and batches_idx[1].count(0) == 1    # the padded duplicate of row 0
+    else:
+        batches_idx = [list(range(i, min(i + 2 * BS_LOCAL, N_TEXT))) for i in range(0, N_TEXT, 2 * BS_LOCAL)]
+    tb = [tuple(x[torch.tensor(b)] for x in sets) + (torch.tensor(b),) for b in batches_idx]
+    ib = [(images, torch.arange(N_IMG))]
+    sd = synth.synth_state_dict(MODEL, 0)
+    score, _ = O.train_one_epoch(sd, tb, ib, N_TEXT, N_IMG, lr=LR, wd=WD, T1=T1, T2=T2, steps=STEPS)
+    for r in (r0, r1):
+        torch.testing.assert_close(r["score"], score, rtol=1e-5, atol=2e-6)
+        assert (r["score"] > -100).all()                                  # every caption row was written
+        for k, v in r["params"].items():
+            if k.startswith("transformer."):
+                torch.testing.assert_close(v, sd[k], rtol=1e-5, atol=1e-7, msg=lambda m, k=k: f"{k}: {m}")
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    assert torch.equal(r0["score"], r1["score"])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode,needle", [("mismatch", "DistributedSampler"), ("tiny_batch", "cannot be cut")])
+def test_train_one_epoch_world2_rejects_bad_wiring_on_every_rank(tmp_path, mode, needle):
+    """A sampler that does not match the process group, or a batch with fewer rows than ranks, must raise on EVERY rank
+    before any collective (a rank failing alone would leave the others waiting: ADVICE r1)."""
+    mp.spawn(_epoch_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    for r in (0, 1):
+        res = torch.load(tmp_path / f"rank{r}.pt", weights_only=True)
+        assert res["err"] is not None and needle in res["err"], res["err"]
+
+
+def test_sampler_without_process_group_is_rejected():
+    """A DistributedSampler over several replicas with args.distributed off would silently adapt on 1/W of the rows."""
+    import types
+    from neat_amd import train_TTA as T
+    from neat_amd.data import create_loader, create_sampler
+    sets, images = _epoch_inputs()
+    ds = [_TextDS(sets), _ImageDS(images)]
+    lt, li = create_loader(ds, create_sampler(ds, [False, False], 2, 0), batch_size=[4, 4], num_workers=[0, 0],
+                           is_trains=[False, False], collate_fns=[None, None])
+    assert T._distributed_sampler(lt) is not None and T._distributed_sampler(li) is not None
+    with pytest.raises(RuntimeError, match="args.distributed is off"):
+        T._loader_is_sharded(lt, 1, 0, "text")

@@ -424,6 +424,50 @@ def test_loss_row_shards_match_single_call():
     np.testing.assert_allclose(ls[1:].numpy(), l.cpu()[1:].numpy(), rtol=1e-5)
 
 
+def test_loss_at_config3_global_batch_row_shards():
+    """BASELINE config 3: global B = 2048 rows of D = 768 cut into 8 shards of 256.  Shards row0 in {0, 256, 1792}
+    against the oracle and against the single call over all 2048 rows (gradients bit-equal across the sharding)."""
+    B, D, Bl = 2048, 768, 256
+    t, p, v = _unit(B, D, 1), _unit(B, D, 2), _unit(B, D, 3)
+    t = torch.nn.functional.normalize(t + 0.5 * _unit(1, D, 9), dim=-1)
+    G = _unit(600, D, 4)
+    c = G[torch.randint(0, G.shape[0], (B,), generator=g(5))]          # shared coarse images -> SR ties
+    l_ref, dt_ref, dp_ref, dv_ref = O.tta_loss_fwd_bwd(t, p, v, c, 0.03, 0.07)
+    td, pd, vd, cd = (x.to(DEV) for x in (t, p, v, c))
+    l, dt, dp, dv = ops.tta_loss_fwd_bwd(td, pd, vd, td, cd, 0.03, 0.07)
+    np.testing.assert_allclose(l.cpu().numpy(), l_ref.numpy(), rtol=1e-4)
+    assert rel_l2(dt.cpu(), dt_ref) < 1e-3 and rel_l2(dp.cpu(), dp_ref) < 1e-5 and rel_l2(dv.cpu(), dv_ref) < 1e-4
+    for row0 in (0, 256, 1792):
+        sl = slice(row0, row0 + Bl)
+        l_, a, b_, c_ = ops.tta_loss_fwd_bwd(td[sl].contiguous(), pd[sl].contiguous(), vd[sl].contiguous(), td, cd,
+                                             0.03, 0.07, row0=row0)
+        assert torch.equal(a, dt[sl]) and torch.equal(b_, dp[sl]) and torch.equal(c_, dv[sl]), row0
+        assert abs(l_[0].item() - l[0].item()) < 1e-6
+        assert rel_l2(a.cpu(), dt_ref[sl]) < 1e-3 and rel_l2(c_.cpu(), dv_ref[sl]) < 1e-4
+    # the eight shards' sr / triplet sums add up to the global terms
+    tot = torch.zeros(2)
+    for r in range(B // Bl):
+        sl = slice(r * Bl, (r + 1) * Bl)
+        tot += ops.tta_loss_fwd_bwd(td[sl].contiguous(), pd[sl].contiguous(), vd[sl].contiguous(), td, cd, 0.03, 0.07,
+                                    row0=r * Bl)[0].cpu()[1:]
+    np.testing.assert_allclose(tot.numpy(), l_ref.numpy()[1:], rtol=1e-4)
+
+
+def test_adamw_views_must_stay_attached():
+    from neat_amd.optim import AdamW
+    ps = [torch.nn.Parameter(torch.randn(8, device=DEV)), torch.nn.Parameter(torch.randn(4, device=DEV))]
+    opt = AdamW(ps, lr=1e-3)
+    opt.step()
+    ps[1].grad = None                                   # detaches the gradient view
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        opt.step()
+    ps2 = [torch.nn.Parameter(torch.randn(8, device=DEV))]
+    opt2 = AdamW(ps2, lr=1e-3)
+    ps2[0].data = ps2[0].data.clone()                   # what model.to()/.float() does
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        opt2.step()
+
+
 def test_adamw_matches_torch():
     n = 24576
     p0 = torch.randn(n, generator=g(1)); p_ref = p0.clone().requires_grad_()

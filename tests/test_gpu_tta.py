@@ -65,12 +65,13 @@ def _flat_ln(model):
     return torch.cat([p.detach().flatten() for p in oc.collect_params(model, False)[0]]).cpu()
 
 
-def _run_hip_manual(tag):
+def _run_hip_manual(tag, packed=False):
     """Step the HIP path by hand to expose per-step intermediates; returns dict of results."""
     g = load_golden(tag)
     m = g["meta"]
     cfg = synth.get_cfg(m["model"])
     model, sd = _model(m["model"], m["wseed"])
+    model.pack_tokens = packed
     np.testing.assert_allclose(weight_checksums(sd), g["wsum"], rtol=1e-9)
     tb, ib = make_batches(cfg, m["n_text"], m["n_image"], m["bs_text"], m["bs_image"], m["dseed"])
     out = dict(g=g, m=m, sd=sd, tb=tb, ib=ib)
@@ -121,8 +122,31 @@ class _NoStep:
         pass
 
 
-def _check_against_reference(tag, loss_tol, param_tol):
-    r = _run_hip_manual(tag)
+# Gates on what the optimizer actually receives and does.  The adapted-parameter gate of
+# north_star (rel-L2 <= 1e-3 on the parameter VECTOR) cannot fail on its own: three AdamW steps at lr 2e-4 move a
+# parameter by <= 6e-4, so an implementation that never stepped would score ~8e-4.  These can fail:
+#   grad1_cos / grad1_rel : step-1 LayerNorm gradient vs the reference's autograd gradient;
+#   update_cos / update_rel: the parameter UPDATE (final - initial) vs the reference's update.  Adam's first steps move
+#     every element by ~lr * sign(g) whatever |g| is, so an element whose gradient is smaller than the bf16 noise and
+#     flips sign contributes a full 2*lr error: update_rel ~ 2*sqrt(f) for a flipped fraction f (0.13 <-> f ~ 0.4 %;
+#     `update_sign_flip_frac` in the report is the measured f).  An un-stepped model has update_rel = 1.
+GRAD1_COS_MIN, GRAD1_REL_MAX = 0.999, 0.05
+UPDATE_COS_MIN, UPDATE_REL_MAX = 0.99, 0.15
+
+
+def _update_gate(final, p0, ref_final):
+    """(passes, cos, rel, sign-flip fraction) of the parameter update final - p0 against the reference's."""
+    up, ref = (final - p0).double(), (torch.as_tensor(ref_final) - p0).double()
+    if float(up.norm()) == 0.0:
+        return False, 0.0, 1.0, 1.0
+    cos = min_cosine(up.view(1, -1), ref.view(1, -1))
+    rel = rel_l2(up, ref)
+    flips = float((torch.sign(up) != torch.sign(ref)).double().mean())
+    return (cos >= UPDATE_COS_MIN and rel <= UPDATE_REL_MAX), cos, rel, flips
+
+
+def _check_against_reference(tag, loss_tol, param_tol, packed=False):
+    r = _run_hip_manual(tag, packed)
     g, m = r["g"], r["m"]
     rep = {}
     rep["cos_img"] = min_cosine(r["img_rows"], g["img_rows"])
@@ -147,8 +171,14 @@ def _check_against_reference(tag, loss_tol, param_tol):
     rep["param_rel_steps"] = [rel_l2(s, gs) for s, gs in zip(r["snaps"], g["params_after"])]
     rep["param_rel_final"] = rel_l2(r["final"], g["final_params"])
     p0 = torch.cat([r["sd"][k].flatten() for k in m["names"]])
-    rep["update_cos"] = min_cosine((r["final"] - p0).view(1, -1), (torch.from_numpy(g["final_params"]) - p0).view(1, -1))
-    rep["update_rel"] = rel_l2(r["final"] - p0, torch.from_numpy(g["final_params"]) - p0)
+    ok_update, rep["update_cos"], rep["update_rel"], rep["update_sign_flip_frac"] = _update_gate(
+        r["final"], p0, g["final_params"])
+    # controls: the same gate must FAIL for a model that never stepped and for one that stepped the wrong way
+    noop_ok = _update_gate(p0.clone(), p0, g["final_params"])[0]
+    wrong_ok = _update_gate(2 * p0 - torch.from_numpy(g["final_params"]), p0, g["final_params"])[0]
+    half_ok = _update_gate(p0 + 0.5 * (torch.from_numpy(g["final_params"]) - p0), p0, g["final_params"])[0]
+    rep["control_gate_passes"] = dict(no_step=noop_ok, negated_update=wrong_ok, half_update=half_ok)
+    rep["param_rel_if_never_stepped"] = rel_l2(p0, g["final_params"])
     ref_score = torch.from_numpy(g["score"]) if "score" in g else None
     if ref_score is not None:
         rep["score_max_abs"] = float((r["score"] - ref_score).abs().max())
@@ -166,7 +196,7 @@ def _check_against_reference(tag, loss_tol, param_tol):
     assert mine == pytest.approx(orc, abs=1e-7)
     rep["recall_ref_t2i"] = [float(x) for x in g["recall_t2i"]]
     rep["recall_ref_i2t"] = [float(x) for x in g["recall_i2t"]]
-    _report(tag, rep)
+    _report(tag + ("_packed" if packed else ""), rep)
     print(json.dumps(rep, indent=1))
     # ---- gates ----
     assert rep["cos_img"] >= 0.999 and rep["cos_txt_unnorm"] >= 0.999
@@ -182,6 +212,11 @@ def _check_against_reference(tag, loss_tol, param_tol):
     assert rep["loss_rel"][0] <= 2e-3 and rep["loss_rel"][2] <= 2e-3, rep["loss_rel"]
     assert rep["loss_sr_abs_over_total"] <= loss_tol, rep
     assert rep["param_rel_final"] <= param_tol and max(rep["param_rel_steps"]) <= param_tol
+    # the gates that can fail (see above) + their controls
+    if "grad1_cos" in rep:
+        assert rep["grad1_cos"] >= GRAD1_COS_MIN and rep["grad1_rel"] <= GRAD1_REL_MAX, rep
+    assert ok_update, (rep["update_cos"], rep["update_rel"])
+    assert not noop_ok and not wrong_ok and not half_ok, rep["control_gate_passes"]
     assert rep["coarse_idx_mismatch"] <= max(1, rep["n_idx"] // 20)
     assert rep["score_max_abs"] < 2e-2
     return rep
@@ -197,6 +232,57 @@ def test_vitb32_b32_epoch_vs_reference():
 
 def test_vitb32_b256_epoch_vs_reference():
     _check_against_reference("vitb32_b256", loss_tol=1e-3, param_tol=1e-3)
+
+
+def test_vitl14_b128_epoch_vs_reference():
+    """BASELINE config 3's model (ViT-L-14: text width 768, D = 768, 24 vision layers of width 1024) against the
+    REFERENCE's own run (tests/golden/vitl14_b128.npz; the reference's hard-coded 512-column gallery buffer widened to
+    768, see make_golden.py)."""
+    _check_against_reference("vitl14_b128", loss_tol=1e-3, param_tol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "vitb32_b32", "vitb32_b256"])
+def test_packed_tokens_epoch_vs_reference(tag):
+    """The opt-in packed text batches against the reference's golden vectors, not only against the full-length run."""
+    _check_against_reference(tag, loss_tol=1e-3, param_tol=1e-3, packed=True)
+
+
+def test_vitl14_step_at_config3_shard_vs_oracle():
+    """One full ViT-L-14 adaptation step at config 3's per-GPU shape (Bl = 256 caption rows x 4 variants, D = 768)
+    against the fp32 oracle: features cos >= 0.999, loss within 1e-3, gradient direction.  The oracle's side was computed
+    once on the host by tests/golden/make_oracle_fixtures.py (minutes of CPU time) and is loaded from the fixture."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "golden", "make_oracle_fixtures.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    g = load_golden("vitl14_bl256_oracle_step")
+    m = g["meta"]
+    model, sd = _model(m["model"], m["wseed"])
+    toks, G = fx.inputs(m)                                   # the same seeded integer draws the fixture was made from
+    np.testing.assert_allclose([G.double().sum().item(), G.double().abs().sum().item()], g["gallery_sum"], rtol=1e-9)
+    B = m["B"]
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=m["lr"], weight_decay=m["wd"])
+    with torch.no_grad():
+        feats = [model.encode_text(x[:32].to(DEV), normalize=True).cpu() for x in toks]
+    losses, idx, S = T.tta_step(model, _NoStep(opt), [x.to(DEV) for x in toks], G.to(DEV), m["T1"], m["T2"])
+    grad = opt.flat_grad.detach().cpu().clone()
+    lo, gref = g["losses"], torch.from_numpy(g["grad"])
+    rep = dict(cos=[min_cosine(a, b) for a, b in zip(feats, g["feats"])],
+               loss=[float(x) for x in losses.cpu()], loss_ref=[float(x) for x in lo],
+               loss_total_rel=abs(float(losses.sum()) - float(lo.sum())) / abs(float(lo.sum())),
+               idx_mismatch=int((idx.cpu().numpy() != g["idx"]).sum()),
+               grad_cos=min_cosine(grad.view(1, -1), gref.view(1, -1)), grad_rel=rel_l2(grad, gref),
+               score_max_abs=float((S[:8].cpu() - torch.from_numpy(g["score_rows"])).abs().max()))
+    _report("vitl14_bl256_step_vs_oracle", rep)
+    assert min(rep["cos"]) >= 0.999, rep
+    assert rep["loss_total_rel"] <= 1e-3, rep
+    assert abs(rep["loss"][0] - rep["loss_ref"][0]) <= 2e-3 * abs(rep["loss_ref"][0]), rep
+    assert abs(rep["loss"][2] - rep["loss_ref"][2]) <= 2e-3 * abs(rep["loss_ref"][2]), rep
+    assert rep["idx_mismatch"] <= B // 20 and rep["score_max_abs"] < 2e-2, rep
+    assert rep["grad_cos"] >= GRAD1_COS_MIN and rep["grad_rel"] <= GRAD1_REL_MAX, rep
 
 
 def test_train_one_epoch_dropin_matches_manual_loop():
@@ -331,6 +417,74 @@ def test_data_parallel_step_equals_single_gpu(tmp_path):
     assert rel_l2(r0["params"], _flat_ln(model)) < 2e-5
     torch.testing.assert_close(r0["losses"], losses.cpu(), rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(r0["S"], S.cpu(), rtol=0, atol=2e-3)
+
+
+def _dp_epoch_worker(rank, world, port, out):
+    """train_one_epoch on ViT-B-32 through the package's own create_sampler / create_loader (DistributedSamplers, as the
+    reference's launcher wires them): every rank encodes its half of the gallery and adapts on its half of each batch."""
+    import faulthandler
+    import torch.distributed as dist
+    from neat_amd.data import create_loader, create_sampler
+    from test_dp_gloo import _ImageDS, _TextDS
+    faulthandler.dump_traceback_later(90, exit=True)          # a hang becomes a failure with a stack, not a silent stall
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0 on the 1-GPU box
+    try:
+        model, _ = _model("ViT-B-32", 0)
+        oc.freeze_parameters(model, False)
+        params, _ = oc.collect_params(model, False)
+        opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+        sets, images = _dp_epoch_inputs()
+        ds = [_TextDS(sets), _ImageDS(images)]
+        lt, li = create_loader(ds, create_sampler(ds, [False, False], world, rank), batch_size=[8, 5], num_workers=[0, 0],
+                               is_trains=[False, False], collate_fns=[None, None])
+        args = types.SimpleNamespace(distributed=True, tta_only_visual=False, name="neat", tta_steps=2,
+                                     tta_temperature=0.03, tta_temperature2=0.07)
+        _, score = T.train_one_epoch(model, lambda x: x, lt, li, opt, torch.device(DEV), args)
+        torch.save(dict(score=score.cpu(), params=_flat_ln(model)), os.path.join(out, f"e{rank}.pt"))
+        faulthandler.cancel_dump_traceback_later()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_epoch_inputs():
+    cfg = synth.get_cfg("ViT-B-32")
+    t = cfg["text_cfg"]
+    sets = synth.synth_caption_sets(27, t["context_length"], t["vocab_size"], 55)     # 27 -> 28 rows: batches 16 + 12
+    images = synth.synth_images(13, cfg["vision_cfg"]["image_size"], 56)              # 13 -> 14 images
+    return sets, images
+
+
+@pytest.mark.timeout(400)
+def test_data_parallel_epoch_vitb32_sharded_gallery_equals_single_gpu(tmp_path):
+    """Two ranks, ViT-B-32, DistributedSampler loaders (sharded gallery + all-gather, text batch already local): scores and
+    adapted LN parameters equal the single-GPU epoch on the same global batches up to fp32 reduction order."""
+    import socket
+    import torch.multiprocessing as mp
+    from test_dp_gloo import _sampler_order
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_epoch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "e0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "e1.pt", weights_only=True)
+    sets, images = _dp_epoch_inputs()
+    per_rank = _sampler_order(27, 2)
+    batches_idx = [sum((pr[k:k + 8] for pr in per_rank), []) for k in range(0, len(per_rank[0]), 8)]
+    tb = [tuple(x[torch.tensor(b)] for x in sets) + (torch.tensor(b),) for b in batches_idx]
+    ib = [(images, torch.arange(13))]
+    model, _ = _model("ViT-B-32", 0)
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+    args = types.SimpleNamespace(distributed=False, tta_only_visual=False, name="neat", tta_steps=2,
+                                 tta_temperature=0.03, tta_temperature2=0.07)
+    _, score = T.train_one_epoch(model, lambda x: x, FakeLoader(tb, 27, "text"), FakeLoader(ib, 13, "image"), opt,
+                                 torch.device(DEV), args)
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["score"], r1["score"])   # ranks in lock step
+    assert (r0["score"] > -100).all()
+    assert rel_l2(r0["params"], _flat_ln(model)) < 2e-5
+    torch.testing.assert_close(r0["score"], score.cpu(), rtol=0, atol=2e-3)
 
 
 @pytest.mark.parametrize("name,B", [("neat-tiny", 9), ("ViT-B-32", 6)])
