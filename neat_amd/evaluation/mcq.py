@@ -23,55 +23,56 @@ def _score_batch(model, image_tensor, captions, tokenizer, device):
     return pred.long().cpu()
 
 
+TYPES = ("positive", "negative", "hybrid")
+
+
 def evaluate_model(model, dataloader, args, tokenizer, is_synthetic=False):
-    """mcq.py:10-146: accuracy overall / per question type and the wrong-answer statistics."""
+    """mcq.py:10-146: accuracy overall / per question type and the wrong-answer statistics.
+
+    The reference counts item by item in Python; here every batch contributes (question type, predicted option, hit)
+    triples and ONE bincount over a 3 x 4 x 2 table yields all the statistics it reports.  Option index -> caption type
+    of a WRONG pick: synthetic sets {0: positive, 1: hybrid, 2: hybrid, 3: negative}, others {1: hybrid, 2: positive,
+    3: negative} (option 0 is the correct caption there)."""
     device = getattr(args, "device", "cuda")
     model.eval()
-    total_questions = len(dataloader.dataset)
-    types = ("positive", "negative", "hybrid")
-    correct_answers_by_type = {t: 0 for t in types}
-    total_questions_by_type = {t: 0 for t in types}
-    if is_synthetic:
-        wrong_answer_to_type = {0: "positive", 1: "hybrid", 2: "hybrid", 3: "negative"}
-    else:
-        wrong_answer_to_type = {1: "hybrid", 2: "positive", 3: "negative"}
-    wrong_answer_counts = {k: 0 for k in wrong_answer_to_type}
-    predictions_by_type = {t: 0 for t in types}
-    wrong_answers_by_question_type = {t: {u: 0 for u in types} for t in types}
-    correct_answers_sum = 0
+    option_type = ({0: "positive", 1: "hybrid", 2: "hybrid", 3: "negative"} if is_synthetic
+                   else {1: "hybrid", 2: "positive", 3: "negative"})
+    n_opt = 4
+    table = torch.zeros(len(TYPES) * n_opt * 2, dtype=torch.int64)
     for image_tensor, captions, correct_answer, correct_answer_type in dataloader:
         pred = _score_batch(model, image_tensor, captions, tokenizer, device)
-        correct_answer = torch.as_tensor(correct_answer).cpu()
-        correct_answers_sum += int((pred == correct_answer).sum())
-        for i in range(image_tensor.size(0)):
-            answer_type = correct_answer_type[i]
-            total_questions_by_type[answer_type] += 1
-            if pred[i] == correct_answer[i]:
-                correct_answers_by_type[answer_type] += 1
-                predictions_by_type[answer_type] += 1
-            else:
-                wrong_type = wrong_answer_to_type[int(pred[i])]
-                wrong_answer_counts[int(pred[i])] += 1
-                predictions_by_type[wrong_type] += 1
-                wrong_answers_by_question_type[answer_type][wrong_type] += 1
-
-    def acc(t):
-        return correct_answers_by_type[t] / total_questions_by_type[t] if total_questions_by_type[t] > 0 else float("nan")
-
-    most_common = max(wrong_answer_counts, key=wrong_answer_counts.get)
+        hit = (pred == torch.as_tensor(correct_answer).cpu()).long()
+        qtype = torch.tensor([TYPES.index(t) for t in correct_answer_type], dtype=torch.int64)
+        table += torch.bincount((qtype * n_opt + pred) * 2 + hit, minlength=table.numel())
+    table = table.view(len(TYPES), n_opt, 2)                  # [question type, predicted option, hit]
+    asked = table.sum(dim=(1, 2))
+    right = table[:, :, 1].sum(dim=1)
+    wrong_by_option = table[:, :, 0].sum(dim=0)               # how often each option was picked wrongly
+    wrong_answer_counts = {k: int(wrong_by_option[k]) for k in option_type}
+    predictions_by_type = {t: int(right[i]) for i, t in enumerate(TYPES)}
+    wrong_answers_by_question_type = {t: {u: 0 for u in TYPES} for t in TYPES}
+    for k, wrong_type in option_type.items():
+        predictions_by_type[wrong_type] += int(wrong_by_option[k])
+        for i, t in enumerate(TYPES):
+            wrong_answers_by_question_type[t][wrong_type] += int(table[i, k, 0])
+    stray = int(wrong_by_option.sum()) - sum(wrong_answer_counts.values())
+    if stray:
+        raise KeyError(f"mcq.evaluate_model: {stray} wrong prediction(s) on an option without a caption type "
+                       f"(option 0 is the correct caption outside the synthetic sets)")
     total_wrong = sum(wrong_answer_counts.values())
-    return {
-        "total_accuracy": correct_answers_sum / total_questions,
-        "positive_accuracy": acc("positive"),
-        "negative_accuracy": acc("negative"),
-        "hybrid_accuracy": acc("hybrid"),
-        "most_common_wrong_answer_type": wrong_answer_to_type[most_common],
+    most_common = max(wrong_answer_counts, key=wrong_answer_counts.get)
+    result = {"total_accuracy": int(right.sum()) / len(dataloader.dataset)}
+    for i, t in enumerate(TYPES):
+        result[f"{t}_accuracy"] = int(right[i]) / int(asked[i]) if int(asked[i]) > 0 else float("nan")
+    result.update({
+        "most_common_wrong_answer_type": option_type[most_common],
         # the reference divides by zero when nothing is wrong (mcq.py:134); report NaN instead of raising
-        "wrong_answer_percentages": {wrong_answer_to_type[k]: (v / total_wrong * 100 if total_wrong else float("nan"))
+        "wrong_answer_percentages": {option_type[k]: (v / total_wrong * 100 if total_wrong else float("nan"))
                                      for k, v in wrong_answer_counts.items()},
         "predictions_by_type": predictions_by_type,
         "wrong_answers_by_question_type": wrong_answers_by_question_type,
-    }
+    })
+    return result
 
 
 def evaluate_binary_mcq_model(model, dataloader, args, tokenizer):

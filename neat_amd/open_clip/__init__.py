@@ -2,3 +2,4 @@ from .factory import (add_model_config, collect_params, create_model, create_mod
                       freeze_parameters, get_model_config, list_models, load_checkpoint)
 from .model import CLIP, LayerNorm, VideoCLIP
 from .tokenizer import SimpleTokenizer, get_tokenizer
+from .transform import GpuImageTransform, image_transform

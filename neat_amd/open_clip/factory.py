@@ -82,13 +82,16 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
 
 def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32",
                                 device: Union[str, torch.device] = "cpu", video: bool = False, **kw):
-    """reference factory.py:445-510.  Image preprocessing is host-side I/O outside the accelerated path;
-    the returned transforms are ``None`` (callers feed preprocessed tensors)."""
-    kw.pop("image_mean", None); kw.pop("image_std", None)
+    """reference factory.py:445-510: (model, preprocess_train, preprocess_val).  The transforms are the host half of
+    the image pipeline (-> uint8 [H, W, 3]); resize / ToTensor / Normalize run on the GPU per batch in
+    ``neat_amd.data.GpuImageLoader`` (see open_clip/transform.py)."""
+    from .transform import image_transform
+    mean, std = kw.pop("image_mean", None), kw.pop("image_std", None)
     model = create_model(model_name, pretrained, precision=precision, device=device, **kw)
+    size = get_model_config(model_name)["vision_cfg"]["image_size"]
     if video:
         model = VideoCLIP(model)
-    return model, None, None
+    return model, image_transform(size, True, mean, std), image_transform(size, False, mean, std)
 
 
 def freeze_parameters(model, only_visual):

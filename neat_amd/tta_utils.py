@@ -1,27 +1,8 @@
-"""Host-side helpers with the reference's names (reference src/tta_utils.py): LR schedules (:4-23), rank
-helpers (:233-259) and the LayerNorm export used by the PLIP workflow (:287-341)."""
-import math
-
+"""Host-side helpers of the TTA path with the reference's names (reference src/tta_utils.py): the rank helpers
+train_one_epoch uses (:233-259) and the hand-over of adapted LayerNorm parameters to a HuggingFace CLIP text tower
+(:287-341, the PLIP workflow).  The reference's LR schedules and meters are never called on this path and are not here."""
 import torch
 import torch.distributed as dist
-
-
-def cosine_lr_schedule(optimizer, epoch, max_epoch, init_lr, min_lr):
-    lr = (init_lr - min_lr) * 0.5 * (1. + math.cos(math.pi * epoch / max_epoch)) + min_lr
-    for g in optimizer.param_groups:
-        g['lr'] = lr
-
-
-def warmup_lr_schedule(optimizer, step, max_step, init_lr, max_lr):
-    lr = min(max_lr, init_lr + (max_lr - init_lr) * step / max_step)
-    for g in optimizer.param_groups:
-        g['lr'] = lr
-
-
-def step_lr_schedule(optimizer, epoch, init_lr, min_lr, decay_rate):
-    lr = max(min_lr, init_lr * (decay_rate ** epoch))
-    for g in optimizer.param_groups:
-        g['lr'] = lr
 
 
 def is_dist_avail_and_initialized():
@@ -36,36 +17,42 @@ def get_rank():
     return dist.get_rank() if is_dist_avail_and_initialized() else 0
 
 
-def is_main_process():
-    return get_rank() == 0
+def _text_ln_pairs(model):
+    """(state-dict name, module) of every adapted LayerNorm of the text tower, in block order."""
+    for i, blk in enumerate(model.transformer.resblocks):
+        yield f"transformer.resblocks.{i}.ln_1", blk.ln_1
+        yield f"transformer.resblocks.{i}.ln_2", blk.ln_2
 
 
 def export_text_layernorm_params(model):
-    """Adapted text-tower LN parameters as a {name: cpu tensor} dict (checkpoint / parity dump)."""
+    """The adapted parameters as a {state-dict key: fp32 CPU tensor} dict -- the only state a TTA run produces
+    (24 576 floats for ViT-B-32); ``model.load_state_dict(d, strict=False)`` restores it."""
     out = {}
-    for i, b in enumerate(model.transformer.resblocks):
-        for ln in ("ln_1", "ln_2"):
-            m = getattr(b, ln)
-            out[f"transformer.resblocks.{i}.{ln}.weight"] = m.weight.detach().float().cpu().clone()
-            out[f"transformer.resblocks.{i}.{ln}.bias"] = m.bias.detach().float().cpu().clone()
+    for name, ln in _text_ln_pairs(model):
+        out[name + ".weight"] = ln.weight.detach().float().cpu().clone()
+        out[name + ".bias"] = ln.bias.detach().float().cpu().clone()
     return out
 
 
+@torch.no_grad()
 def replace_text_layernorm_params(hf_model, openai_model):
-    """Copy the adapted text-tower LayerNorm parameters into a HuggingFace CLIPModel
-    (reference tta_utils.py:287-341): resblocks[i].ln_1 -> layers[i].layer_norm1, ln_2 -> layer_norm2."""
-    enc = hf_model.text_model
-    tr = openai_model.transformer
-    n = len(enc.encoder.layers)
-    for i in range(n):
-        hl, ol = enc.encoder.layers[i], tr.resblocks[i]
-        if hasattr(hl, 'layer_norm1'):
-            hl.layer_norm1.weight.data = ol.ln_1.weight.data.detach().clone().to(hl.layer_norm1.weight.device)
-            hl.layer_norm1.bias.data = ol.ln_1.bias.data.detach().clone().to(hl.layer_norm1.bias.device)
-        if hasattr(hl, 'layer_norm2'):
-            hl.layer_norm2.weight.data = ol.ln_2.weight.data.detach().clone().to(hl.layer_norm2.weight.device)
-            hl.layer_norm2.bias.data = ol.ln_2.bias.data.detach().clone().to(hl.layer_norm2.bias.device)
-    if hasattr(tr, 'ln_final') and hasattr(enc, 'final_layer_norm'):
-        enc.final_layer_norm.weight.data = tr.ln_final.weight.data.detach().clone()
-        enc.final_layer_norm.bias.data = tr.ln_final.bias.data.detach().clone()
-    return n
+    """Write the text tower's LayerNorm parameters of ``openai_model`` (open_clip layout) into a HuggingFace ``CLIPModel``:
+    block i's ln_1 / ln_2 become ``text_model.encoder.layers[i].layer_norm1 / layer_norm2``, and ``ln_final`` becomes
+    ``text_model.final_layer_norm`` when both sides have one (same mapping and return value as reference
+    tta_utils.py:287-341: the number of HF layers visited).  Values are copied into the HF parameters in place, on
+    whatever device and dtype they live."""
+    hf_text = hf_model.text_model
+    layers = hf_text.encoder.layers
+    blocks = openai_model.transformer.resblocks
+    for hf_layer, blk in zip(layers, blocks):
+        for hf_name, src in (("layer_norm1", blk.ln_1), ("layer_norm2", blk.ln_2)):
+            dst = getattr(hf_layer, hf_name, None)
+            if dst is not None:
+                dst.weight.copy_(src.weight.detach().to(dst.weight))
+                dst.bias.copy_(src.bias.detach().to(dst.bias))
+    src_final = getattr(openai_model.transformer, "ln_final", None)     # as the reference looks it up (absent in CLIP)
+    dst_final = getattr(hf_text, "final_layer_norm", None)
+    if src_final is not None and dst_final is not None:
+        dst_final.weight.copy_(src_final.weight.detach().to(dst_final.weight))
+        dst_final.bias.copy_(src_final.bias.detach().to(dst_final.bias))
+    return len(layers)

@@ -64,3 +64,37 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_integration_md_stub_binds_against_the_library():
+    """The ctypes stub printed in INTEGRATION.md is executed as written (only the library path is substituted) and every
+    binding it makes must agree with neat_amd.lib.SIGNATURES."""
+    import ctypes as C
+    from neat_amd import lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"## ctypes stub.*?```python\n(.*?)```", md, flags=re.S).group(1)
+    assert "libneat_hip.so" in block
+    block = block.replace('"libneat_hip.so"', repr(lib.LIB_PATH))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    bound = {v.__name__: v for v in ns.values() if isinstance(v, C._CFuncPtr) and hasattr(v, "__name__")}
+    assert len(bound) >= 30
+    for name, fn in bound.items():
+        res, args = lib.SIGNATURES[name]
+        assert list(fn.argtypes) == list(args), name
+        assert fn.restype == res, name
+
+
+def test_create_model_and_transforms_returns_transforms():
+    import numpy as np
+    import torch
+    from neat_amd import open_clip as oc
+    model, tr, val = oc.create_model_and_transforms("neat-tiny", device="cpu")
+    assert tr.size == val.size == 32 and tr.is_train and not val.is_train
+    img = np.random.default_rng(0).integers(0, 255, (20, 30, 3), dtype=np.uint8)
+    out = val(img)
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (20, 30, 3) and out.is_contiguous()
+    from PIL import Image
+    assert torch.equal(val(Image.fromarray(img)), out)
+    with pytest.raises(TypeError):
+        val(torch.zeros(3, 20, 30))

@@ -285,6 +285,59 @@ def test_vitl14_step_at_config3_shard_vs_oracle():
     assert rep["grad_cos"] >= GRAD1_COS_MIN and rep["grad_rel"] <= GRAD1_REL_MAX, rep
 
 
+def test_gradient_error_attribution():
+    """Where does the 2-4 % error of the step-1 LayerNorm gradient (grad1_rel) come from?  ViT-B-32, 32 rows.
+    (a) forward: the loss gradient w.r.t. the FEATURES, computed by the same fp32 loss kernel from HIP features and from
+        the oracle's fp32 features (same coarse images) -- the share caused by bf16 noise in the forward pass;
+    (b) backward: the oracle's feature gradient pushed through the HIP backward pass vs through the oracle's -- the
+        share caused by bf16 operands in the data-gradient GEMMs.  Reported in parity_report.json; DESIGN.md §2."""
+    name = "ViT-B-32"
+    model, sd = _model(name, 0)
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    B = 32
+    toks = synth.synth_caption_sets(B, t["context_length"], t["vocab_size"], 1234)
+    G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"], generator=torch.Generator().manual_seed(3)), dim=-1)
+    oc.freeze_parameters(model, False)
+    params, _ = oc.collect_params(model, False)
+    opt = AdamW(params, lr=2e-4, weight_decay=1e-3)
+    tower = model._text_tower()
+    text, pos, neg, inv = [x.to(DEV) for x in toks]
+    feats, ctx = tower.forward(torch.cat([text, pos, inv, neg], dim=0), True, True, n_grad=3 * B)
+    th, ph, vh = feats[:B], feats[B:2 * B], feats[2 * B:3 * B]
+    names = O.adapted_param_names(sd)
+    fo, caches = [], []
+    for x in (toks[0], toks[1], toks[3]):
+        f, c = O.encode_text_fwd(sd, x, True, save=True)
+        fo.append(f); caches.append(c)
+    n_o = O.encode_text_fwd(sd, toks[2], True)[0]
+    c_o, _, _ = O.coarse_align_t2i(fo[0], fo[1], n_o, G)
+    cd = c_o.to(DEV)
+    _, dth, dph, dvh = ops.tta_loss_fwd_bwd(th, ph, vh, th, cd, 0.03, 0.07)
+    to, po, vo = (f.to(DEV) for f in fo)
+    _, dto, dpo, dvo = ops.tta_loss_fwd_bwd(to, po, vo, to, cd, 0.03, 0.07)
+    # (b) the oracle's feature gradient through both backward passes
+    grads = T._ln_grad_views(model)
+    tower.backward(ctx, torch.cat([dto, dpo, dvo], dim=0), grads, accumulate=False)
+    g_hip = opt.flat_grad.detach().cpu().clone()
+    g_or = {}
+    for c, d in zip(caches, (dto, dpo, dvo)):
+        O.encode_text_bwd(sd, c, d.cpu(), g_or)
+    g_ref = torch.cat([g_or[k].flatten() for k in names])
+    # (a)+(b): HIP features' gradient through the HIP backward = what the step really uses
+    tower.backward(ctx, torch.cat([dth, dph, dvh], dim=0), grads, accumulate=False)
+    g_all = opt.flat_grad.detach().cpu().clone()
+    rep = dict(feature_centered_rel=rel_l2(th.cpu() - th.cpu().mean(0), fo[0] - fo[0].mean(0)),
+               dfeat_rel_from_forward_noise=[rel_l2(a.cpu(), b.cpu()) for a, b in ((dth, dto), (dph, dpo), (dvh, dvo))],
+               grad_rel_backward_only=rel_l2(g_hip, g_ref), grad_rel_total=rel_l2(g_all, g_ref),
+               grad_cos_backward_only=min_cosine(g_hip.view(1, -1), g_ref.view(1, -1)),
+               grad_cos_total=min_cosine(g_all.view(1, -1), g_ref.view(1, -1)))
+    _report("gradient_error_attribution_vitb32_b32", rep)
+    print(json.dumps(rep, indent=1))
+    assert rep["grad_cos_total"] >= GRAD1_COS_MIN and rep["grad_rel_total"] <= GRAD1_REL_MAX, rep
+    assert rep["grad_rel_backward_only"] <= GRAD1_REL_MAX, rep
+
+
 def test_train_one_epoch_dropin_matches_manual_loop():
     """The public entry point (same signature as the reference) == the hand-stepped loop, bit for bit."""
     r = _run_hip_manual("tiny")
@@ -576,7 +629,11 @@ def test_offline_eval_and_mcq_match_oracle():
     assert sum(m["predictions_by_type"].values()) == n_img
     b2 = [(imgs[i:i + 6], [o[i:i + 6] for o in opts[:2]], answers[i:i + 6] % 2) for i in range(0, n_img, 6)]
     mb2 = MQ.evaluate_binary_mcq_model(model, _ListLoader(b2, n_img), args, tok)
-    assert 0.0 <= mb2["total_accuracy"] <= 1.0
+    logits2 = logits[:, :2]
+    clear2 = (logits2[:, 0] - logits2[:, 1]).abs() > 2e-2
+    ref_acc2 = float((logits2.argmax(1) == answers % 2).float().mean())
+    assert abs(mb2["total_accuracy"] - ref_acc2) <= float((~clear2).sum()) / n_img + 1e-6
+    assert int(clear2.sum()) >= n_img // 2              # the comparison above is not vacuous
     # the driver the CLI calls after train_one_epoch (evaluation/utils.py:9-66): result keys + one results.jsonl line
     import json as _json
     import tempfile

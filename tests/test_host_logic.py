@@ -1,0 +1,166 @@
+"""CPU: host-side logic of the callers either side of the hot path -- the LayerNorm hand-over to a HuggingFace-shaped
+text tower (reference tta_utils.py:287-341), the MCQ statistics (reference evaluation/mcq.py:38-146) and the model factory's
+activation guard.  No kernels run here: the scoring call is replaced by scripted predictions."""
+import types
+
+import pytest
+import torch
+
+from neat_amd import open_clip as oc, synth, tta_utils
+from neat_amd.evaluation import mcq as MQ
+
+
+# ------------------------------------------------------------------ LN export / hand-over
+class _HFLayer(torch.nn.Module):
+    def __init__(self, c, with_ln2=True):
+        super().__init__()
+        self.layer_norm1 = torch.nn.LayerNorm(c)
+        if with_ln2:
+            self.layer_norm2 = torch.nn.LayerNorm(c)
+
+
+class _HFClip(torch.nn.Module):
+    """The attribute layout of transformers.CLIPModel that replace_text_layernorm_params touches."""
+
+    def __init__(self, c, n, dtype=torch.float32):
+        super().__init__()
+        self.text_model = torch.nn.Module()
+        self.text_model.encoder = torch.nn.Module()
+        self.text_model.encoder.layers = torch.nn.ModuleList([_HFLayer(c, with_ln2=(i != 1)) for i in range(n)])
+        self.text_model.final_layer_norm = torch.nn.LayerNorm(c)
+        self.to(dtype)
+
+
+def _adapted_tiny():
+    model = oc.create_model("neat-tiny", device="cpu")
+    model.load_state_dict(synth.synth_state_dict("neat-tiny", 0))
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for blk in model.transformer.resblocks:                     # pretend TTA moved every LN parameter
+            for ln in (blk.ln_1, blk.ln_2):
+                ln.weight.add_(torch.randn(ln.weight.shape, generator=g) * 0.01)
+                ln.bias.add_(torch.randn(ln.bias.shape, generator=g) * 0.01)
+    return model
+
+
+def test_replace_text_layernorm_params_into_hf_shaped_module():
+    model = _adapted_tiny()
+    n = len(model.transformer.resblocks)
+    C = model.transformer.resblocks[0].ln_1.weight.numel()
+    hf = _HFClip(C, n, dtype=torch.float64)                        # another dtype: values are cast, storage is kept
+    before_final = hf.text_model.final_layer_norm.weight.clone()
+    ptr = hf.text_model.encoder.layers[0].layer_norm1.weight.data_ptr()
+    assert tta_utils.replace_text_layernorm_params(hf, model) == n
+    for i, (hl, blk) in enumerate(zip(hf.text_model.encoder.layers, model.transformer.resblocks)):
+        assert torch.equal(hl.layer_norm1.weight, blk.ln_1.weight.double()) and torch.equal(hl.layer_norm1.bias, blk.ln_1.bias.double())
+        if i != 1:                                                  # layer 1 has no layer_norm2: skipped, not an error
+            assert torch.equal(hl.layer_norm2.weight, blk.ln_2.weight.double())
+    assert hf.text_model.encoder.layers[0].layer_norm1.weight.data_ptr() == ptr          # in place
+    # CLIP keeps ln_final outside model.transformer (open_clip/model.py:245), so -- exactly as in the reference -- the HF
+    # final_layer_norm is left alone
+    assert torch.equal(hf.text_model.final_layer_norm.weight, before_final)
+    # a tower that does carry transformer.ln_final hands it over too
+    model.transformer.ln_final = torch.nn.LayerNorm(C)
+    torch.nn.init.normal_(model.transformer.ln_final.weight)
+    tta_utils.replace_text_layernorm_params(hf, model)
+    assert torch.equal(hf.text_model.final_layer_norm.weight, model.transformer.ln_final.weight.double())
+
+
+def test_export_text_layernorm_params_round_trip():
+    model = _adapted_tiny()
+    d = tta_utils.export_text_layernorm_params(model)
+    _, names = oc.collect_params(model, False)
+    assert sorted(d) == sorted("transformer." + n for n in names)
+    fresh = oc.create_model("neat-tiny", device="cpu")
+    fresh.load_state_dict(synth.synth_state_dict("neat-tiny", 0))
+    missing = fresh.load_state_dict(d, strict=False)
+    assert not missing.unexpected_keys
+    for a, b in zip(oc.collect_params(fresh, False)[0], oc.collect_params(model, False)[0]):
+        assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ MCQ statistics
+def _count_item_by_item(preds, answers, qtypes, option_type):
+    """Plain restatement of what the reference reports (mcq.py:38-146), one item at a time."""
+    T = ("positive", "negative", "hybrid")
+    right = {t: 0 for t in T}; asked = {t: 0 for t in T}; pbt = {t: 0 for t in T}
+    wac = {k: 0 for k in option_type}; wbq = {t: {u: 0 for u in T} for t in T}
+    for p, a, q in zip(preds, answers, qtypes):
+        asked[q] += 1
+        if p == a:
+            right[q] += 1; pbt[q] += 1
+        else:
+            wac[p] += 1; pbt[option_type[p]] += 1; wbq[q][option_type[p]] += 1
+    return right, asked, pbt, wac, wbq
+
+
+@pytest.mark.parametrize("synthetic", [True, False])
+def test_mcq_statistics_equal_item_by_item_count(monkeypatch, synthetic):
+    g = torch.Generator().manual_seed(5 + synthetic)
+    n, bs = 57, 8
+    answers = torch.randint(0, 4, (n,), generator=g) if synthetic else torch.zeros(n, dtype=torch.int64)
+    preds = torch.randint(0, 4, (n,), generator=g)
+    if not synthetic:
+        preds[::3] = 0
+    qtypes = [("positive", "negative", "hybrid")[int(i)] for i in torch.randint(0, 3, (n,), generator=g)]
+    batches, cursor = [], []
+    for i in range(0, n, bs):
+        batches.append((torch.zeros(len(preds[i:i + bs]), 1), None, answers[i:i + bs], qtypes[i:i + bs]))
+        cursor.append(preds[i:i + bs])
+    it = iter(cursor)
+    monkeypatch.setattr(MQ, "_score_batch", lambda *a, **k: next(it))
+
+    class L:
+        dataset = list(range(n))
+
+        def __iter__(self):
+            return iter(batches)
+
+    class M:
+        def eval(self):
+            pass
+
+    out = MQ.evaluate_model(M(), L(), types.SimpleNamespace(device="cpu"), None, is_synthetic=synthetic)
+    option_type = ({0: "positive", 1: "hybrid", 2: "hybrid", 3: "negative"} if synthetic
+                   else {1: "hybrid", 2: "positive", 3: "negative"})
+    right, asked, pbt, wac, wbq = _count_item_by_item(preds.tolist(), answers.tolist(), qtypes, option_type)
+    assert out["total_accuracy"] == sum(right.values()) / n
+    for t in right:
+        assert out[f"{t}_accuracy"] == right[t] / asked[t]
+    assert out["predictions_by_type"] == pbt and out["wrong_answers_by_question_type"] == wbq
+    tot = sum(wac.values())
+    # the reference keys this dict by caption type, so the two "hybrid" options of the synthetic sets collapse: last wins
+    want = {}
+    for k, v in wac.items():
+        want[option_type[k]] = v / tot * 100
+    assert out["wrong_answer_percentages"] == want
+    assert out["most_common_wrong_answer_type"] == option_type[max(wac, key=wac.get)]
+    assert sum(pbt.values()) == n
+
+
+def test_mcq_wrong_pick_of_option_zero_outside_synthetic_sets_raises(monkeypatch):
+    monkeypatch.setattr(MQ, "_score_batch", lambda *a, **k: torch.tensor([0, 1]))
+
+    class L:
+        dataset = [0, 1]
+
+        def __iter__(self):
+            return iter([(torch.zeros(2, 1), None, torch.tensor([1, 1]), ["positive", "negative"])])
+
+    class M:
+        def eval(self):
+            pass
+
+    with pytest.raises(KeyError):
+        MQ.evaluate_model(M(), L(), types.SimpleNamespace(device="cpu"), None, is_synthetic=False)
+
+
+# ------------------------------------------------------------------ factory
+def test_pretrained_checkpoint_needs_an_explicit_quick_gelu(tmp_path):
+    sd = synth.synth_state_dict("neat-tiny", 0)
+    ck = tmp_path / "w.pt"
+    torch.save(sd, ck)
+    with pytest.raises(RuntimeError, match="QuickGELU"):
+        oc.create_model("neat-tiny", pretrained=str(ck), device="cpu")
+    m = oc.create_model("neat-tiny", pretrained=str(ck), device="cpu", force_quick_gelu=True)
+    assert torch.equal(m.text_projection.detach(), sd["text_projection"])
