@@ -220,17 +220,31 @@ int neat_adamw_flat(float* p, const float* g, float* m, float* v, long n, double
 /* ---- retrieval scoring, evaluation/retrieval.py:280-301 ---- */
 /* Row-wise top-k of a strided f32 matrix (element (r,c) at scores[r*ld_row + c*ld_col]; one of the
  * strides must be 1 -> accepts scores and scores.T).  idx i32 [R,k] descending, ties -> lowest index;
- * val f32 [R,k] (may be NULL).  k <= 32.  ws: neat_topk_ws_bytes(R,Ncol,k) bytes. */
+ * val f32 [R,k] (may be NULL).  k <= 32.  ws: neat_topk_ws_bytes(R,Ncol,k) bytes, 256-B aligned, always required
+ * (row flags + partial lists).  Selection runs in two tiers with identical results: short per-lane lists that prove
+ * their own sufficiency (HBM-bound), then the exact k-entry lists on the rows that could not prove it. */
 long neat_topk_ws_bytes(int R, int Ncol, int k);
 int neat_topk_rows(const float* scores, long ld_row, long ld_col, int R, int Ncol, int k, int32_t* idx,
                    float* val, void* ws, void* stream);
 /* recall[r] = |topk(r) ∩ positives(r)| / |positives(r)| with positives a strided uint8/bool matrix */
 int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, long ld_row, long ld_col, int R,
                           int Ncol, int k, float* recall, void* stream);
+/* Recall for several cut-offs from ONE top-K list per row, positives given as owner vectors (the caption -> image list
+ * the reference builds its bool matrix from, evaluation/retrieval.py:229-240) instead of a dense matrix: column c is a
+ * positive of row r iff row_owner[r] == c (text -> image; row_owner i32 [R] or NULL) or col_owner[c] == r (image -> text;
+ * col_owner i32 [Ncol] or NULL).  idx i32 [R,K] from neat_topk_rows; npos i32 [R] = positives per row (NULL: 1);
+ * ks i32 [nk] ascending cut-offs (DEVICE array); recall f32 [nk, R] = |top-ks[q](r) ∩ positives(r)| / npos[r], the value
+ * recall_at_k returns (:298-300).  One pass over the score matrix then serves k = 1, 5, 10 (:243-250 makes three). */
+int neat_recall_owner_topk(const int32_t* idx, int R, int K, const int32_t* row_owner, const int32_t* col_owner,
+                           const int32_t* npos, const int32_t* ks, int nk, float* recall, void* stream);
 /* median-rank support, evaluation/retrieval.py:186-214: rank[r] (1-based, scores descending, equal scores by
  * index) of the best-ranked positive of row r; 0 if the row has none.  scores / pos strided like neat_topk_rows. */
 int neat_best_positive_rank(const float* scores, long ld_row, long ld_col, const uint8_t* pos, long pld_row,
                             long pld_col, int R, int Ncol, int32_t* rank, void* stream);
+/* the same rank with the positives as ONE owner vector (see neat_recall_owner_topk): row_owner i32 [R] (the positive of
+ * row r is column row_owner[r]) or col_owner i32 [Ncol] (the positives of row r are the columns c with col_owner[c] == r) */
+int neat_best_positive_rank_owner(const float* scores, long ld_row, long ld_col, const int32_t* row_owner,
+                                  const int32_t* col_owner, int R, int Ncol, int32_t* rank, void* stream);
 /* multiple-choice scoring, evaluation/mcq.py:92-97, :199-205: img f32 [B,D], txt f32 [nopt,B,D] ->
  * logits f32 [B,nopt] = einsum('bf,nbf->bn') (may be NULL), pred i32 [B] = argmax_n (first max) */
 int neat_mcq_scores(const float* img, const float* txt, float* logits, int32_t* pred, int B, int nopt, int D,

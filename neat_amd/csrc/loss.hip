@@ -10,57 +10,105 @@
 
 namespace neat {
 
+// ---- exact-fp32 tile GEMM on the matrix cores ----
+// v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per
+// product, /opt/skills/guides/cdna_hip_programming.md §3), so the products below are the SAME numbers the earlier VALU
+// kernels produced (acc = fmaf(a_k, b_k, acc), k ascending) at up to 3x their rate and with the VALU left free.
+// Block = 64 x 64 outputs, 4 waves as 2 x 2, one 32 x 32 accumulator tile per wave and product; operands pass through
+// k-major LDS slabs of 16 k (double buffered, the next slab's global loads in flight under the MFMAs).
 constexpr int SG_T = 64;   // output tile
 constexpr int SG_K = 16;   // k slab
 constexpr int SG_LD = SG_T + 4;
+constexpr int SG_SLAB = SG_K * SG_LD;       // floats per operand slab
 
-// loads a [64 x 16] slab of a K-contiguous matrix (rows clamped) and stores it k-major into LDS
-__device__ __forceinline__ void sg_load(const float* __restrict__ src, int rows, int K, int r0, int k0, float* dst) {
-    const int r = threadIdx.x >> 2, kq = threadIdx.x & 3;
-    int gr = r0 + r;
-    gr = gr < rows ? gr : rows - 1;
-    const float4 v = *reinterpret_cast<const float4*>(src + (long)gr * K + k0 + kq * 4);
-    dst[(kq * 4 + 0) * SG_LD + r] = v.x;
-    dst[(kq * 4 + 1) * SG_LD + r] = v.y;
-    dst[(kq * 4 + 2) * SG_LD + r] = v.z;
-    dst[(kq * 4 + 3) * SG_LD + r] = v.w;
-}
-
-__device__ __forceinline__ void sg_fma(const float* As, const float* Bs, float (&acc)[4][4], int ty, int tx) {
-#pragma unroll
-    for (int k = 0; k < SG_K; ++k) {
-        const float4 a = *reinterpret_cast<const float4*>(As + k * SG_LD + ty * 4);
-        const float4 b = *reinterpret_cast<const float4*>(Bs + k * SG_LD + tx * 4);
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-}
-
-// C[M,N] = A[M,K] . B[N,K]^T
-__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                          float* __restrict__ C, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[SG_K * SG_LD], Bs[SG_K * SG_LD];
-    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += SG_K) {
-        sg_load(A, M, K, m0, k0, As);
-        sg_load(B, N, K, n0, k0, Bs);
-        __syncthreads();
-        sg_fma(As, Bs, acc, ty, tx);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= M) continue;
+// A [64 x 16] operand slab in registers: 4 floats per thread.
+//   row-major operand (element (m,k) at src[m*ld + k], "NT"): thread -> row t>>2, k quad t&3 (one 16-B load);
+//   k-major operand   (element (k,m) at src[k*ld + m], "T"):  thread -> k t>>4, rows 4*(t&15)..+3 (scalar loads: no
+//   alignment assumed); k >= K reads as zero, which leaves an fmaf chain unchanged.
+template <bool KMAJOR>
+__device__ __forceinline__ float4 sg_fetch(const float* __restrict__ src, int rows, int K, long ld, int r0, int k0) {
+    if constexpr (!KMAJOR) {
+        int gr = r0 + (threadIdx.x >> 2);
+        gr = gr < rows ? gr : rows - 1;
+        return *reinterpret_cast<const float4*>(src + (long)gr * ld + k0 + (threadIdx.x & 3) * 4);
+    } else {
+        const int k = k0 + (threadIdx.x >> 4);
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n < N) C[(long)m * N + n] = acc[i][j];
+            int m = r0 + (threadIdx.x & 15) * 4 + j;
+            m = m < rows ? m : rows - 1;
+            v[j] = k < K ? src[(long)k * ld + m] : 0.0f;
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void sg_put(float* dst, float4 v) {
+    if constexpr (!KMAJOR) {
+        const int r = threadIdx.x >> 2, kq = threadIdx.x & 3;
+        dst[(kq * 4 + 0) * SG_LD + r] = v.x;
+        dst[(kq * 4 + 1) * SG_LD + r] = v.y;
+        dst[(kq * 4 + 2) * SG_LD + r] = v.z;
+        dst[(kq * 4 + 3) * SG_LD + r] = v.w;
+    } else {
+        *reinterpret_cast<float4*>(dst + (threadIdx.x >> 4) * SG_LD + (threadIdx.x & 15) * 4) = v;
+    }
+}
+// lane's fragment element of k-pair kk: A[i = lane&31][k = 2kk + (lane>>5)] (same map for the B operand)
+__device__ __forceinline__ float sg_frag(const float* slab, int kk, int off32, int lane) {
+    return slab[(2 * kk + (lane >> 5)) * SG_LD + off32 + (lane & 31)];
+}
+// accumulator register r of a 32 x 32 tile: row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+__device__ __forceinline__ int sg_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// one problem of a launch: C[M,N] = A . B^T over K, exact fp32
+struct SgProb {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long lda, ldb;
+};
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(SgProb p0, SgProb p1) {
+    __shared__ __attribute__((aligned(16))) float As[2][SG_SLAB], Bs[2][SG_SLAB];
+    const SgProb p = blockIdx.z == 0 ? p0 : p1;
+    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
+    if (m0 >= p.M || n0 >= p.N) return;                         // uniform per block (the two problems share one grid)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int ns = (p.K + SG_K - 1) / SG_K;
+    float4 ra = sg_fetch<A_KM>(p.A, p.M, p.K, p.lda, m0, 0), rb = sg_fetch<B_KM>(p.B, p.N, p.K, p.ldb, n0, 0);
+    sg_put<A_KM>(As[0], ra);
+    sg_put<B_KM>(Bs[0], rb);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        if (s + 1 < ns) {
+            ra = sg_fetch<A_KM>(p.A, p.M, p.K, p.lda, m0, (s + 1) * SG_K);
+            rb = sg_fetch<B_KM>(p.B, p.N, p.K, p.ldb, n0, (s + 1) * SG_K);
+        }
+        const float* as = As[s & 1];
+        const float* bs = Bs[s & 1];
+#pragma unroll
+        for (int kk = 0; kk < SG_K / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_frag(as, kk, wm, lane), sg_frag(bs, kk, wn, lane), acc, 0, 0, 0);
+        if (s + 1 < ns) {
+            sg_put<A_KM>(As[(s + 1) & 1], ra);
+            sg_put<B_KM>(Bs[(s + 1) & 1], rb);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn + (lane & 31);
+    if (n < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm + sg_row(r, lane);
+            if (m < p.M) p.C[(long)m * p.N + n] = acc[r];
         }
     }
 }
@@ -71,69 +119,104 @@ __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restric
                                                           const float* __restrict__ neg, const float* __restrict__ G,
                                                           float* __restrict__ S, float* __restrict__ pval,
                                                           int* __restrict__ pidx, int B, int N, int D, int ntn) {
-    __shared__ __attribute__((aligned(16))) float Qs[SG_K * SG_LD], Ps[SG_K * SG_LD], Ns[SG_K * SG_LD], Gs[SG_K * SG_LD];
+    __shared__ __attribute__((aligned(16))) float Qs[2][SG_SLAB], Ps[2][SG_SLAB], Ns[2][SG_SLAB], Gs[2][SG_SLAB];
+    __shared__ float rval[2][SG_T];
+    __shared__ int ridx[2][SG_T];
     const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    float aq[4][4] = {}, ap[4][4] = {}, an[4][4] = {};
-    for (int k0 = 0; k0 < D; k0 += SG_K) {
-        sg_load(q, B, D, m0, k0, Qs);
-        sg_load(pos, B, D, m0, k0, Ps);
-        sg_load(neg, B, D, m0, k0, Ns);
-        sg_load(G, N, D, n0, k0, Gs);
-        __syncthreads();
-        sg_fma(Qs, Gs, aq, ty, tx);
-        sg_fma(Ps, Gs, ap, ty, tx);
-        sg_fma(Ns, Gs, an, ty, tx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 aq, ap, an;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aq[r] = ap[r] = an[r] = 0.0f;
+    const int ns = D / SG_K;
+    float4 rq = sg_fetch<false>(q, B, D, D, m0, 0), rp = sg_fetch<false>(pos, B, D, D, m0, 0),
+           rn = sg_fetch<false>(neg, B, D, D, m0, 0), rg = sg_fetch<false>(G, N, D, D, n0, 0);
+    sg_put<false>(Qs[0], rq);
+    sg_put<false>(Ps[0], rp);
+    sg_put<false>(Ns[0], rn);
+    sg_put<false>(Gs[0], rg);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        if (s + 1 < ns) {
+            const int k0 = (s + 1) * SG_K;
+            rq = sg_fetch<false>(q, B, D, D, m0, k0);
+            rp = sg_fetch<false>(pos, B, D, D, m0, k0);
+            rn = sg_fetch<false>(neg, B, D, D, m0, k0);
+            rg = sg_fetch<false>(G, N, D, D, n0, k0);
+        }
+        const int b = s & 1;
+#pragma unroll
+        for (int kk = 0; kk < SG_K / 2; ++kk) {
+            const float g = sg_frag(Gs[b], kk, wn, lane);
+            aq = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_frag(Qs[b], kk, wm, lane), g, aq, 0, 0, 0);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_frag(Ps[b], kk, wm, lane), g, ap, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x2f32(sg_frag(Ns[b], kk, wm, lane), g, an, 0, 0, 0);
+        }
+        if (s + 1 < ns) {
+            sg_put<false>(Qs[b ^ 1], rq);
+            sg_put<false>(Ps[b ^ 1], rp);
+            sg_put<false>(Ns[b ^ 1], rn);
+            sg_put<false>(Gs[b ^ 1], rg);
+        }
         __syncthreads();
     }
+    const int n = n0 + wn + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm + sg_row(r, lane);
+        const int m = m0 + row;
         float best = -INFINITY;
         int bi = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n < N) {
-                if (m < B) S[(long)m * N + n] = aq[i][j];
-                const float a = ap[i][j] * (1.0f - fmaxf(an[i][j], 0.0f));
-                if (a > best) { best = a; bi = n; }
-            }
+        if (n < N) {
+            if (m < B) S[(long)m * N + n] = aq[r];
+            const float a = ap[r] * (1.0f - fmaxf(an[r], 0.0f));
+            if (a > best) { best = a; bi = n; }
         }
-        // reduce over the 16 lanes (tx) that share this row; ties -> lowest index
+        // the 32 lanes of a half-wave hold the 32 columns of this row; ties -> lowest index
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 16);
-            const int oi = __shfl_xor(bi, o, 16);
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
-        if (tx == 0 && m < B) {
+        if ((lane & 31) == 0) { rval[wave & 1][row] = best; ridx[wave & 1][row] = bi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SG_T) {
+        const int m = m0 + threadIdx.x;
+        float best = rval[0][threadIdx.x];
+        int bi = ridx[0][threadIdx.x];
+        const float ov = rval[1][threadIdx.x];
+        const int oi = ridx[1][threadIdx.x];
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if (m < B) {
             pval[(long)m * ntn + blockIdx.x] = best;
             pidx[(long)m * ntn + blockIdx.x] = bi;
         }
     }
 }
 
-__global__ void coarse_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
-                                    const float* __restrict__ G, int32_t* __restrict__ idx_out,
-                                    float* __restrict__ coarse, int ntn, int D) {
-    __shared__ int sidx;
-    const int m = blockIdx.x;
-    if (threadIdx.x == 0) {
-        float best = -INFINITY;
-        int bi = 0;
-        bool any = false;
-        for (int t = 0; t < ntn; ++t) {
-            const float v = pval[(long)m * ntn + t];
-            if (!any || v > best) { best = v; bi = pidx[(long)m * ntn + t]; any = true; }
-        }
-        if (bi == 0x7fffffff) bi = 0;  // all-NaN row: torch returns the NaN position; never hit with finite features
-        sidx = bi;
-        idx_out[m] = bi;
+// one wavefront per caption row: (max, first argmax) over the column tiles, then the gallery row is copied out
+__global__ __launch_bounds__(64) void coarse_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                          const float* __restrict__ G, int32_t* __restrict__ idx_out,
+                                                          float* __restrict__ coarse, int ntn, int D) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = lane; t < ntn; t += 64) {
+        const float v = pval[(long)m * ntn + t];
+        const int i = pidx[(long)m * ntn + t];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
     }
-    __syncthreads();
-    const int j = sidx;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) coarse[(long)m * D + d] = G[(long)j * D + d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;  // all-NaN row: torch returns the NaN position; never hit with finite features
+    if (lane == 0) idx_out[m] = bi;
+    for (int d = lane; d < D; d += 64) coarse[(long)m * D + d] = G[(long)bi * D + d];
 }
 
 // ---- loss rows ----
@@ -157,10 +240,9 @@ __device__ __forceinline__ float blk_max(float v, float* red) {
 }
 
 // row j of Z (= coarse_j . text_i, unscaled): entropy H_j and dL/dZ_ji written in place
-__global__ __launch_bounds__(256) void entropy_row_kernel(float* __restrict__ Z, float* __restrict__ Hrow, int B,
-                                                          float invT1) {
-    __shared__ float red[8];
-    float* z = Z + (long)blockIdx.x * B;
+__device__ __forceinline__ void entropy_row(float* __restrict__ Z, float* __restrict__ Hrow, int row, int B, float invT1,
+                                            float* red) {
+    float* z = Z + (long)row * B;
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < B; i += blockDim.x) mx = fmaxf(mx, z[i] * invT1);
     mx = blk_max(mx, red);
@@ -178,15 +260,13 @@ __global__ __launch_bounds__(256) void entropy_row_kernel(float* __restrict__ Z,
         const float lp = z[i] * invT1 - lse;
         z[i] = -expf(lp) * (lp + h) / (float)B;
     }
-    if (threadIdx.x == 0) Hrow[blockIdx.x] = h;
+    if (threadIdx.x == 0) Hrow[row] = h;
 }
 
 // local row i of U (= inv_i . coarse_j): hinge max and its first argmax
-__global__ __launch_bounds__(256) void sr_row_kernel(const float* __restrict__ U, float* __restrict__ srm,
-                                                     int* __restrict__ srj, int B, int row0) {
-    __shared__ float rv[8];
-    __shared__ int ri[8];
-    const int i = blockIdx.x, gi = row0 + i;
+__device__ __forceinline__ void sr_row(const float* __restrict__ U, float* __restrict__ srm, int* __restrict__ srj, int i,
+                                       int B, int row0, float* rv, int* ri) {
+    const int gi = row0 + i;
     const float* u = U + (long)i * B;
     const float diag = u[gi];
     float best = -INFINITY;
@@ -213,12 +293,24 @@ __global__ __launch_bounds__(256) void sr_row_kernel(const float* __restrict__ U
     }
 }
 
-// gradients for local row i: dtext, dpos, dinv; triplet row term
+// ONE launch for the row passes of both [.,B] matrices: blocks 0..B-1 take the entropy rows of Z, blocks B..B+Bl-1 the
+// semantics-reversion rows of U
+__global__ __launch_bounds__(256) void loss_rows_kernel(float* __restrict__ Z, float* __restrict__ Hrow,
+                                                        const float* __restrict__ U, float* __restrict__ srm,
+                                                        int* __restrict__ srj, int B, int row0, float invT1) {
+    __shared__ float red[8];
+    __shared__ int ri[8];
+    if ((int)blockIdx.x < B) entropy_row(Z, Hrow, blockIdx.x, B, invT1, red);
+    else sr_row(U, srm, srj, (int)blockIdx.x - B, B, row0, red, ri);
+}
+
+// gradients for local row i: dtext (in: sum_j dZ[j,gi] coarse[j,:], from the tile GEMM; out: the gradient), dpos, dinv;
+// triplet row term
 __global__ __launch_bounds__(256) void loss_grad_kernel(
     const float* __restrict__ text, const float* __restrict__ pos, const float* __restrict__ inv,
-    const float* __restrict__ coarse_all, const float* __restrict__ dZ, const int* __restrict__ srj,
-    float* __restrict__ dtext, float* __restrict__ dpos, float* __restrict__ dinv, float* __restrict__ trirow, int B,
-    int row0, int D, float invT1, float invT2) {
+    const float* __restrict__ coarse_all, const int* __restrict__ srj, float* __restrict__ dtext,
+    float* __restrict__ dpos, float* __restrict__ dinv, float* __restrict__ trirow, int B, int row0, int D, float invT1,
+    float invT2) {
     __shared__ float red[8];
     const int i = blockIdx.x, gi = row0 + i;
     const float* t = text + (long)i * D;
@@ -238,8 +330,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
     const float* cg = coarse_all + (long)gi * D;
     const float* cj = coarse_all + (long)(js >= 0 ? js : gi) * D;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float acc = 0.f;
-        for (int j = 0; j < B; ++j) acc = fmaf(dZ[(long)j * B + gi], coarse_all[(long)j * D + d], acc);
+        const float acc = dtext[(long)i * D + d];
         const float gtv = (t[d] - v[d] + 1e-6f) / dtv * invB;
         const float gtp = (t[d] - p[d] + 1e-6f) / dtp * invB;
         dtext[(long)i * D + d] = acc * invT1 - gtv + 5.0f * gtp;
@@ -285,10 +376,17 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+template <bool A_KM, bool B_KM>
+static void launch_sg(const SgProb& p0, const SgProb* p1, hipStream_t s) {
+    const int M = p1 ? (p0.M > p1->M ? p0.M : p1->M) : p0.M, N = p1 ? (p0.N > p1->N ? p0.N : p1->N) : p0.N;
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KM, B_KM>), dim3(cdiv(N, SG_T), cdiv(M, SG_T), p1 ? 2 : 1), dim3(256), 0, s,
+                       p0, p1 ? *p1 : p0);
+}
+
 int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
     NEAT_REQUIRE(A && B && C, NEAT_ERR_ARG, "gemm_f32_nt: null pointer");
     NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % SG_K == 0, NEAT_ERR_SHAPE, "gemm_f32_nt: K=%d must be a multiple of 16", K);
-    hipLaunchKernelGGL(gemm_f32_nt_kernel, dim3(cdiv(N, SG_T), cdiv(M, SG_T)), dim3(256), 0, s, A, B, C, M, N, K);
+    launch_sg<false, false>(SgProb{A, B, C, M, N, K, K, K}, nullptr, s);
     NEAT_LAUNCH_CHECK("gemm_f32_nt");
     return NEAT_OK;
 }
@@ -314,7 +412,7 @@ extern "C" int neat_coarse_align(const float* q, const float* pos, const float* 
     hipLaunchKernelGGL(coarse_tile_kernel, dim3(ntn, cdiv(B, SG_T)), dim3(256), 0, s, q, pos, neg, G, S_out, pval, pidx, B,
                        N, D, ntn);
     NEAT_LAUNCH_CHECK("neat_coarse_align(tile)");
-    hipLaunchKernelGGL(coarse_final_kernel, dim3(B), dim3(128), 0, s, pval, pidx, G, idx_out, coarse_out, ntn, D);
+    hipLaunchKernelGGL(coarse_final_kernel, dim3(B), dim3(64), 0, s, pval, pidx, G, idx_out, coarse_out, ntn, D);
     NEAT_LAUNCH_CHECK("neat_coarse_align(final)");
     return NEAT_OK;
 }
@@ -379,14 +477,14 @@ extern "C" int neat_tta_loss_fwd_bwd(const float* text, const float* pos, const 
     float* srm = Hrow + B;
     int* srj = reinterpret_cast<int*>(srm + Bl);
     float* trirow = srm + 2 * Bl;
-    // Z[j,i] = coarse_j . text_i ; U[i,j] = inv_i . coarse_j
-    hipLaunchKernelGGL(gemm_f32_nt_kernel, dim3(cdiv(B, SG_T), cdiv(B, SG_T)), dim3(256), 0, s, coarse_all, text_all, Z, B,
-                       B, D);
-    hipLaunchKernelGGL(gemm_f32_nt_kernel, dim3(cdiv(B, SG_T), cdiv(Bl, SG_T)), dim3(256), 0, s, inv, coarse_all, U, Bl, B,
-                       D);
-    hipLaunchKernelGGL(entropy_row_kernel, dim3(B), dim3(256), 0, s, Z, Hrow, B, 1.0f / T1);
-    hipLaunchKernelGGL(sr_row_kernel, dim3(Bl), dim3(256), 0, s, U, srm, srj, B, row0);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(Bl), dim3(256), 0, s, text, pos, inv, coarse_all, Z, srj, dtext, dpos, dinv,
+    // Z[j,i] = coarse_j . text_i ; U[i,j] = inv_i . coarse_j -- both products in ONE launch
+    const SgProb pz{coarse_all, text_all, Z, B, B, D, D, D}, pu{inv, coarse_all, U, Bl, B, D, D, D};
+    launch_sg<false, false>(pz, &pu, s);
+    hipLaunchKernelGGL(loss_rows_kernel, dim3(B + Bl), dim3(256), 0, s, Z, Hrow, U, srm, srj, B, row0, 1.0f / T1);
+    // dtext <- (dZ^T coarse) for the local rows: a GEMM with both operands k-major (k = the B rows of dZ / coarse), so the
+    // walk down a column of dZ is a coalesced slab load instead of one strided read per output element
+    launch_sg<true, true>(SgProb{Z + row0, coarse_all, dtext, Bl, D, B, B, D}, nullptr, s);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(Bl), dim3(256), 0, s, text, pos, inv, coarse_all, srj, dtext, dpos, dinv,
                        trirow, B, row0, D, 1.0f / T1, 1.0f / T2);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, Hrow, srm, trirow, losses, B, Bl, 1.0f / T2);
     NEAT_LAUNCH_CHECK("neat_tta_loss_fwd_bwd");

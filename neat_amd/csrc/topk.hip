@@ -38,6 +38,22 @@ struct TopList {
             }
         }
     }
+    // insert() that also says what LEFT: x itself when it does not make the list, else the entry pushed off the end
+    // (-inf while the list is not full).  Callers keep the maximum of what left to prove a short list was enough.
+    __device__ __forceinline__ float insert_drop(float x, int idx) {
+        if (!(x > v[KP - 1])) return x;
+        bool shifting = false;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            if (shifting || x > v[j]) {
+                const float tv = v[j]; const int ti = i[j];
+                v[j] = x; i[j] = idx;
+                x = tv; idx = ti;
+                shifting = true;
+            }
+        }
+        return x;
+    }
     // general insert for merging lists whose index order is arbitrary
     __device__ __forceinline__ void insert_tie(float x, int idx) {
         bool shifting = false;
@@ -58,18 +74,56 @@ struct TopList {
     }
 };
 
-template <int KP>
-__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, long ld_row, int R, int Ncol,
-                                                        int k, int32_t* __restrict__ idx, float* __restrict__ val) {
+// ---- selection in two tiers --------------------------------------------------------------------------------------------
+// A full k-entry list per lane makes the pass VALU-bound: a lane sees only Ncol/64 values, so most of them enter its list
+// (382 us for 25 014 x 5 000 = 1.3 TB/s).  The fast kernels keep SHORT_M = 4 entries per lane and the maximum of every
+// value that left a list ("lost").  The k winners of the row are all inside the merged short lists unless some lane
+// held more than 4 of them -- in which case one of them left that lane's list, and lost >= the k-th merged value says so.
+// Such rows (about 1 in 10^5 on continuous scores; every row of a matrix full of ties) are flagged in need[] and redone
+// by the exact kernels below, which skip every other row.  Results are identical to the exact kernels' on every input.
+constexpr int SHORT_M = 4;
+
+// VEC: every lane reads 16 B (4 consecutive columns) per step, two steps in flight -- needs 16-B aligned rows
+// (scores % 16 == 0 and ld_row % 4 == 0, checked by the launcher); otherwise 4-B loads.
+template <int M, bool VEC>
+__global__ __launch_bounds__(256) void topk_rows_fast_kernel(const float* __restrict__ scores, long ld_row, int R,
+                                                             int Ncol, int k, int32_t* __restrict__ idx,
+                                                             float* __restrict__ val, int* __restrict__ need) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         const float* row = scores + (long)r * ld_row;
-        TopList<KP> tl;
+        TopList<M> tl;
         tl.init();
-        for (int c = lane; c < Ncol; c += 64) tl.insert(row[c], c);
+        float lost = -INFINITY;
+#define TK_INS(x, c) lost = fmaxf(lost, tl.insert_drop((x), (c)))
+        if constexpr (VEC) {
+            const int nvec = Ncol >> 2;
+            const float4* row4 = reinterpret_cast<const float4*>(row);
+            int g = lane;
+            for (; g + 192 < nvec; g += 256) {                        // four 16-B loads in flight per lane
+                const float4 a = row4[g], b = row4[g + 64], c4 = row4[g + 128], d = row4[g + 192];
+                const int ca = g * 4, cb = ca + 256, cc = ca + 512, cd = ca + 768;
+                TK_INS(a.x, ca); TK_INS(a.y, ca + 1); TK_INS(a.z, ca + 2); TK_INS(a.w, ca + 3);
+                TK_INS(b.x, cb); TK_INS(b.y, cb + 1); TK_INS(b.z, cb + 2); TK_INS(b.w, cb + 3);
+                TK_INS(c4.x, cc); TK_INS(c4.y, cc + 1); TK_INS(c4.z, cc + 2); TK_INS(c4.w, cc + 3);
+                TK_INS(d.x, cd); TK_INS(d.y, cd + 1); TK_INS(d.z, cd + 2); TK_INS(d.w, cd + 3);
+            }
+            for (; g < nvec; g += 64) {
+                const float4 a = row4[g];
+                const int ca = g * 4;
+                TK_INS(a.x, ca); TK_INS(a.y, ca + 1); TK_INS(a.z, ca + 2); TK_INS(a.w, ca + 3);
+            }
+            const int c = (nvec << 2) + lane;                         // the last Ncol % 4 columns: largest indices
+            if (c < Ncol) TK_INS(row[c], c);
+        } else {
+            for (int c = lane; c < Ncol; c += 64) TK_INS(row[c], c);
+        }
+#undef TK_INS
+        float bv = -INFINITY;
+        int bi = IMAX;
         for (int round = 0; round < k; ++round) {
-            float bv = tl.v[0];
-            int bi = tl.i[0];
+            bv = tl.v[0];
+            bi = tl.i[0];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(bv, o, 64);
@@ -82,49 +136,196 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
                 if (val) val[(long)r * k + round] = bv;
             }
         }
+        lost = wave_max(lost);
+        // bv = the k-th selected value.  A value that left some lane's list and is >= bv may belong to the top k
+        // (> bv: certainly; == bv: by the lowest-index tie rule) -> exact pass for this row.
+        if (lane == 0) need[r] = (M < k && lost >= bv) || bi == IMAX;
     }
 }
 
-// transposed view: element (r, c) at scores[r + c*ld_col]; thread <-> logical row r, blockIdx.y <-> c-range
-template <int KP>
-__global__ __launch_bounds__(64) void topk_cols_partial_kernel(const float* __restrict__ scores, long ld_col, int R,
-                                                               int Ncol, int nsplit, float* __restrict__ pv,
-                                                               int* __restrict__ pi) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= R) return;
+// The exact kernels (a k-entry list per lane).  need == NULL: every row; else only rows with need[r] != 0.
+// One 256-thread block per row whatever the layout (with ld_col != 1, a transposed view, a lane's loads are strided -- slow
+// per element, but this tier only sees the rows the fast tier flagged): a k-entry list per lane, then k rounds of a
+// block-wide arg-max (wave shuffles, then the four wave winners through LDS).
+template <int KP, bool VEC>
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, long ld_row, long ld_col, int R,
+                                                        int Ncol, int k, int32_t* __restrict__ idx,
+                                                        float* __restrict__ val, const int* __restrict__ need) {
+    __shared__ float wv[2][4];
+    __shared__ int wi[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = threadIdx.x;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        if (need && !need[r]) continue;                               // block-uniform
+        const float* row = scores + (long)r * ld_row;
+        TopList<KP> tl;
+        tl.init();
+        if constexpr (VEC) {
+            // a thread's columns come in increasing order (4t + j, then + 1024), which insert() relies on
+            const int nvec = Ncol >> 2;
+            const float4* row4 = reinterpret_cast<const float4*>(row);
+            int g = t;
+            for (; g + 256 < nvec; g += 512) {
+                const float4 a = row4[g], b = row4[g + 256];
+                const int ca = g * 4, cb = (g + 256) * 4;
+                tl.insert(a.x, ca); tl.insert(a.y, ca + 1); tl.insert(a.z, ca + 2); tl.insert(a.w, ca + 3);
+                tl.insert(b.x, cb); tl.insert(b.y, cb + 1); tl.insert(b.z, cb + 2); tl.insert(b.w, cb + 3);
+            }
+            if (g < nvec) {
+                const float4 a = row4[g];
+                const int ca = g * 4;
+                tl.insert(a.x, ca); tl.insert(a.y, ca + 1); tl.insert(a.z, ca + 2); tl.insert(a.w, ca + 3);
+            }
+            const int c = (nvec << 2) + t;                            // the last Ncol % 4 columns: largest indices
+            if (c < Ncol) tl.insert(row[c], c);
+        } else {
+            int c = t;
+            for (; c + 7 * 256 < Ncol; c += 8 * 256) {                // eight independent (possibly strided) loads in flight
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = row[(long)(c + j * 256) * ld_col];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tl.insert(x[j], c + j * 256);
+            }
+            for (; c < Ncol; c += 256) tl.insert(row[(long)c * ld_col], c);
+        }
+        for (int round = 0; round < k; ++round) {
+            float bv = tl.v[0];
+            int bi = tl.i[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { wv[round & 1][wave] = bv; wi[round & 1][wave] = bi; }
+            __syncthreads();                                          // one barrier per round: the slots alternate
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float ov = wv[round & 1][w];
+                const int oi = wi[round & 1][w];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (tl.i[0] == bi && bi != IMAX) tl.pop();
+            if (t == 0) {
+                idx[(long)r * k + round] = bi;
+                if (val) val[(long)r * k + round] = bv;
+            }
+        }
+        __syncthreads();                                              // before the next row reuses the slots
+    }
+}
+
+// fast tier, transposed view: a lane owns RPL consecutive logical rows (RPL = 4: one 16-B load covers them; a wave reads
+// 1 KiB of every column), blockIdx.y owns a column range; per row a SHORT_M list + the maximum of what left it.
+// partials, row-major so that ONE wavefront can finish a row: pv / pi [R][nsplit][SHORT_M], plost [R][nsplit].
+template <int M, int RPL>
+__global__ __launch_bounds__(64) void topk_cols_fast_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
+                                                            int nsplit, float* __restrict__ pv, int* __restrict__ pi,
+                                                            float* __restrict__ plost) {
+    const int r0 = (blockIdx.x * 64 + threadIdx.x) * RPL;
+    if (r0 >= R) return;
     const int per = (Ncol + nsplit - 1) / nsplit;
     const int c0 = blockIdx.y * per;
     const int c1 = min(Ncol, c0 + per);
-    TopList<KP> tl;
-    tl.init();
-    for (int c = c0; c < c1; ++c) tl.insert(scores[(long)c * ld_col + r], c);
-    float* ov = pv + ((long)r * nsplit + blockIdx.y) * KP;
-    int* oi = pi + ((long)r * nsplit + blockIdx.y) * KP;
+    TopList<M> tl[RPL];
+    float lost[RPL];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) { ov[j] = tl.v[j]; oi[j] = tl.i[j]; }
+    for (int q = 0; q < RPL; ++q) { tl[q].init(); lost[q] = -INFINITY; }
+    auto take = [&](const float* x, int c) {
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) lost[q] = fmaxf(lost[q], tl[q].insert_drop(x[q], c));
+    };
+    auto load = [&](int c, float* x) {
+        const float* p = scores + (long)c * ld_col + r0;
+        if constexpr (RPL == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+            x[0] = *p;
+        }
+    };
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {                        // four independent loads in flight per lane
+        float x[4][RPL];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load(c + j, x[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) take(x[j], c + j);
+    }
+    for (; c < c1; ++c) {
+        float x[RPL];
+        load(c, x);
+        take(x, c);
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const int r = r0 + q;
+        if (r < R) {
+            const long o = ((long)r * nsplit + blockIdx.y) * M;
+#pragma unroll
+            for (int j = 0; j < M; ++j) { pv[o + j] = tl[q].v[j]; pi[o + j] = tl[q].i[j]; }
+            plost[(long)r * nsplit + blockIdx.y] = lost[q];
+        }
+    }
 }
 
-template <int KP>
-__global__ __launch_bounds__(64) void topk_cols_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
-                                                             int R, int nsplit, int k, int32_t* __restrict__ idx,
-                                                             float* __restrict__ val) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+// finish of the fast tier: one wavefront per row over that row's nsplit * M candidates (value, column), exactly the row
+// kernel's scheme -- a short list per lane plus what left it, k rounds of a wave-wide arg-max, and the sufficiency proof.
+template <int M>
+__global__ __launch_bounds__(256) void topk_pairs_finish_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                                const float* __restrict__ plost, int R, int nsplit, int k,
+                                                                int32_t* __restrict__ idx, float* __restrict__ val,
+                                                                int* __restrict__ need) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
     if (r >= R) return;
-    TopList<KP> tl;
+    const int ncand = nsplit * M;
+    const float* cv = pv + (long)r * ncand;
+    const int* ci = pi + (long)r * ncand;
+    TopList<M> tl;
     tl.init();
-    for (int s = 0; s < nsplit; ++s)
-        for (int j = 0; j < KP; ++j) {
-            const long o = ((long)r * nsplit + s) * KP + j;
-            const int ci = pi[o];
-            if (ci != IMAX) tl.insert_tie(pv[o], ci);
-        }
-    // static-index copy out
+    float lost = -INFINITY;
+    for (int s = lane; s < nsplit; s += 64) lost = fmaxf(lost, plost[(long)r * nsplit + s]);
+    for (int e = lane; e < ncand; e += 64) {
+        // walk the candidates rank-major (all first entries of the splits, then all second entries ...): a row's winners
+        // are mostly first entries, and this spreads those over all 64 lanes instead of every fourth one
+        const int c = (e % nsplit) * M + e / nsplit;
+        float x = cv[c];
+        int xi = ci[c];
+        if (xi == IMAX) continue;
+        // insert keeping (value desc, column asc); what falls off the end is remembered
+        if (!(x > tl.v[M - 1] || (x == tl.v[M - 1] && xi < tl.i[M - 1]))) { lost = fmaxf(lost, x); continue; }
+        bool shifting = false;
 #pragma unroll
-    for (int j = 0; j < KP; ++j)
-        if (j < k) {
-            idx[(long)r * k + j] = tl.i[j];
-            if (val) val[(long)r * k + j] = tl.v[j];
+        for (int j = 0; j < M; ++j) {
+            if (shifting || x > tl.v[j] || (x == tl.v[j] && xi < tl.i[j])) {
+                const float tv = tl.v[j]; const int ti = tl.i[j];
+                tl.v[j] = x; tl.i[j] = xi;
+                x = tv; xi = ti;
+                shifting = true;
+            }
         }
+        if (xi != IMAX) lost = fmaxf(lost, x);
+    }
+    float bv = -INFINITY;
+    int bi = IMAX;
+    for (int round = 0; round < k; ++round) {
+        bv = tl.v[0];
+        bi = tl.i[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (tl.i[0] == bi && bi != IMAX) tl.pop();
+        if (lane == 0) {
+            idx[(long)r * k + round] = bi;
+            if (val) val[(long)r * k + round] = bv;
+        }
+    }
+    lost = wave_max(lost);
+    if (lane == 0) need[r] = (M < k && lost >= bv) || bi == IMAX;
 }
 
 // recall[r] = (# of top-k indices that are positives) / (# positives in row r)
@@ -134,7 +335,22 @@ __global__ __launch_bounds__(256) void recall_rows_kernel(const int32_t* __restr
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         const uint8_t* row = pos + (long)r * ld_row;
         float n = 0.f;
-        for (int c = lane; c < Ncol; c += 64) n += row[c] ? 1.f : 0.f;
+        int c = 0;
+        if ((((uintptr_t)row) & 15) == 0) {               // 16 flags per load
+            const int nv = Ncol >> 4;
+            for (int g = lane; g < nv; g += 64) {
+                const uint4 w = reinterpret_cast<const uint4*>(row)[g];
+                const uint32_t ws_[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t x = ws_[j];
+                    x = (x | (x >> 1) | (x >> 2) | (x >> 3) | (x >> 4) | (x >> 5) | (x >> 6) | (x >> 7)) & 0x01010101u;   // byte != 0
+                    n += (float)__popc(x);
+                }
+            }
+            c = nv << 4;
+        }
+        for (c += lane; c < Ncol; c += 64) n += row[c] ? 1.f : 0.f;
         n = wave_sum(n);
         float tp = 0.f;
         for (int j = lane; j < k; j += 64) {
@@ -160,6 +376,30 @@ __global__ __launch_bounds__(64) void recall_cols_kernel(const int32_t* __restri
     recall[r] = tp / n;
 }
 
+
+// Recall from ONE top-K list per row for several cut-offs at once, with the positives given as owner vectors instead
+// of a dense [R, Ncol] bool matrix (NegBench: caption t belongs to image txt2img[t]; reference evaluation/retrieval.py:
+// 229-240 builds the bool matrix from exactly this list).  Column c is a positive of row r iff
+//   row_owner != NULL and row_owner[r] == c      (text -> image direction: one positive per caption), or
+//   col_owner != NULL and col_owner[c] == r      (image -> text direction: the captions owned by image r).
+// npos[r] = number of positives of row r (NULL: 1).  recall[q*R + r] = |top-ks[q](r) ∩ positives(r)| / npos[r].
+__global__ __launch_bounds__(256) void recall_owner_kernel(const int32_t* __restrict__ idx, int R, int K,
+                                                           const int32_t* __restrict__ row_owner,
+                                                           const int32_t* __restrict__ col_owner,
+                                                           const int32_t* __restrict__ npos, const int32_t* __restrict__ ks,
+                                                           int nk, float* __restrict__ recall) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int own = row_owner ? row_owner[r] : -1;
+    const float n = npos ? (float)npos[r] : 1.0f;
+    int q = 0, tp = 0;
+    for (int j = 0; j < K && q < nk; ++j) {
+        const int c = idx[(long)r * K + j];
+        if (c >= 0) tp += ((row_owner && c == own) || (col_owner && col_owner[c] == r)) ? 1 : 0;
+        while (q < nk && ks[q] == j + 1) recall[(long)q++ * R + r] = (float)tp / n;   // 0/0 -> NaN like torch
+    }
+    for (; q < nk; ++q) recall[(long)q * R + r] = (float)tp / n;                     // cut-offs beyond K: all of the list
+}
 
 // ---- median-rank support, evaluation/retrieval.py:186-214: rank (1-based, descending scores) of the best-ranked
 // positive of every row; equal scores are ordered by index, like the top-k kernels.  0 = row has no positive.
@@ -210,6 +450,60 @@ __global__ __launch_bounds__(256) void best_positive_rank_kernel(const float* __
     if (threadIdx.x == 0) rank[r] = 1 + sc[0] + sc[1] + sc[2] + sc[3];
 }
 
+// The same rank with the positives given as owner vectors (see recall_owner_kernel): no dense bool matrix is read.
+// row_owner: the single positive of row r is column row_owner[r]; col_owner: the positives of row r are the columns c
+// with col_owner[c] == r (a 4-B-per-column scan that stays in L2).
+__global__ __launch_bounds__(256) void best_positive_rank_owner_kernel(const float* __restrict__ scores, long ld_row,
+                                                                       long ld_col, const int32_t* __restrict__ row_owner,
+                                                                       const int32_t* __restrict__ col_owner, int R,
+                                                                       int Ncol, int32_t* __restrict__ rank) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int sc[4];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* srow = scores + (long)r * ld_row;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (row_owner) {
+        const int c = row_owner[r];
+        if (c >= 0 && c < Ncol) { best = srow[(long)c * ld_col]; bi = c; }
+    } else {
+        for (int c = threadIdx.x; c < Ncol; c += 256) {
+            if (col_owner[c] == r) {
+                const float v = srow[(long)c * ld_col];
+                if (bi == 0x7fffffff || v > best) { best = v; bi = c; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+        __syncthreads();
+        best = sv[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (si[w] != 0x7fffffff && (bi == 0x7fffffff || sv[w] > best || (sv[w] == best && si[w] < bi))) { best = sv[w]; bi = si[w]; }
+    }
+    if (bi == 0x7fffffff) {
+        if (threadIdx.x == 0) rank[r] = 0;
+        return;
+    }
+    int cnt = 0;
+    for (int c = threadIdx.x; c < Ncol; c += 256) {
+        const float v = srow[(long)c * ld_col];
+        cnt += (v > best || (v == best && c < bi)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) sc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[r] = 1 + sc[0] + sc[1] + sc[2] + sc[3];
+}
+
 // ---- multiple-choice scoring, evaluation/mcq.py:92-97 and :199-205: logits[b,n] = <img[b], txt[n,b]>,
 // pred[b] = argmax_n (first max).  One wavefront per image.
 __global__ __launch_bounds__(256) void mcq_scores_kernel(const float* __restrict__ img, const float* __restrict__ txt,
@@ -243,7 +537,40 @@ static inline int topk_kp(int k) { return k <= 1 ? 1 : (k <= 8 ? 8 : (k <= 16 ? 
 
 using namespace neat;
 
-extern "C" long neat_topk_ws_bytes(int R, int Ncol, int k) { return (long)R * topk_nsplit(Ncol) * topk_kp(k) * 8 + 256; }
+// column splits of the fast transposed-view kernel: enough 64-lane blocks (a block covers 256 logical rows) for ~16
+// waves per CU, at least 32 columns each
+static inline int topk_fast_nsplit(int R, int Ncol) {
+    const int rowblocks = cdiv(R, 256);
+    int s = cdiv(4096, rowblocks);
+    const int cap = Ncol / 32 > 1 ? Ncol / 32 : 1;
+    s = s > cap ? cap : s;
+    return s < 1 ? 1 : s;
+}
+
+struct TopkWs {                // carve-up of the caller's workspace (all 256-B aligned)
+    int* need;                 // [R]
+    float* fv; int* fi;        // fast tier: [R][nsf][SHORT_M]
+    float* flost;              // [R][nsf]
+    long bytes;
+};
+static TopkWs topk_carve(void* ws, int R, int Ncol, int k) {
+    auto up = [](long b) { return (b + 255) / 256 * 256; };
+    const long nsf = topk_fast_nsplit(R, Ncol);
+    char* p = reinterpret_cast<char*>(ws);
+    long off = 0;
+    TopkWs w;
+    w.need = reinterpret_cast<int*>(p + off); off += up((long)R * 4);
+    w.fv = reinterpret_cast<float*>(p + off); off += up(nsf * SHORT_M * (long)R * 4);
+    w.fi = reinterpret_cast<int*>(p + off); off += up(nsf * SHORT_M * (long)R * 4);
+    w.flost = reinterpret_cast<float*>(p + off); off += up(nsf * (long)R * 4);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" long neat_topk_ws_bytes(int R, int Ncol, int k) {
+    if (R <= 0 || Ncol <= 0 || k < 1) return 256;
+    return topk_carve(nullptr, R, Ncol, k).bytes + 256;
+}
 
 #define TOPK_DISPATCH(KPV, ...)                 \
     switch (KPV) {                              \
@@ -259,19 +586,34 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
     NEAT_REQUIRE(R > 0 && Ncol > 0 && k >= 1 && k <= 32 && k <= Ncol, NEAT_ERR_SHAPE,
                  "neat_topk_rows: need 1 <= k <= min(32, Ncol); got k=%d Ncol=%d", k, Ncol);
     NEAT_REQUIRE(ld_col == 1 || ld_row == 1, NEAT_ERR_SHAPE, "neat_topk_rows: one stride must be 1 (got %ld, %ld)", ld_row, ld_col);
+    NEAT_REQUIRE(ws && (uintptr_t)ws % 256 == 0, NEAT_ERR_ARG, "neat_topk_rows: workspace missing or not 256-B aligned");
     hipStream_t s = (hipStream_t)stream;
     const int kp = topk_kp(k);
+    const TopkWs w = topk_carve(ws, R, Ncol, k);
+    // the fast tier, then the exact tier on the rows it flagged (none at all when k <= SHORT_M)
+    int grid = cdiv(R, 4);
+    grid = grid > 8192 ? 8192 : grid;
+    const int xgrid = R > 16384 ? 16384 : R;                          // exact tier: a block per row
     if (ld_col == 1) {
-        int grid = cdiv(R, 4);
-        grid = grid > 8192 ? 8192 : grid;
-        TOPK_DISPATCH(kp, hipLaunchKernelGGL(topk_rows_kernel<KP>, dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val));
+        const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_row % 4 == 0);
+        if (vec) hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, true>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
+        else hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, false>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
+        if (k > SHORT_M) {
+            if (vec) {
+                TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, true>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, 1L, R, Ncol, k, idx, val, w.need));
+            } else {
+                TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, false>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, 1L, R, Ncol, k, idx, val, w.need));
+            }
+        }
     } else {
-        NEAT_REQUIRE(ws, NEAT_ERR_ARG, "neat_topk_rows: transposed view needs a workspace");
-        const int ns = topk_nsplit(Ncol);
-        float* pv = reinterpret_cast<float*>(ws);
-        int* pi = reinterpret_cast<int*>(pv + (long)R * ns * kp);
-        TOPK_DISPATCH(kp, hipLaunchKernelGGL(topk_cols_partial_kernel<KP>, dim3(cdiv(R, 64), ns), dim3(64), 0, s, scores, ld_col, R, Ncol, ns, pv, pi);
-                      hipLaunchKernelGGL(topk_cols_merge_kernel<KP>, dim3(cdiv(R, 64)), dim3(64), 0, s, pv, pi, R, ns, k, idx, val));
+        const int nsf = topk_fast_nsplit(R, Ncol);
+        const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_col % 4 == 0) && (R % 4 == 0);
+        if (vec) hipLaunchKernelGGL((topk_cols_fast_kernel<SHORT_M, 4>), dim3(cdiv(R, 256), nsf), dim3(64), 0, s, scores, ld_col, R, Ncol, nsf, w.fv, w.fi, w.flost);
+        else hipLaunchKernelGGL((topk_cols_fast_kernel<SHORT_M, 1>), dim3(cdiv(R, 64), nsf), dim3(64), 0, s, scores, ld_col, R, Ncol, nsf, w.fv, w.fi, w.flost);
+        hipLaunchKernelGGL((topk_pairs_finish_kernel<SHORT_M>), dim3(cdiv(R, 4)), dim3(256), 0, s, w.fv, w.fi, w.flost, R, nsf, k, idx, val, w.need);
+        if (k > SHORT_M) {
+            TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, false>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, ld_col, R, Ncol, k, idx, val, w.need));
+        }
     }
     NEAT_LAUNCH_CHECK("neat_topk_rows");
     return NEAT_OK;
@@ -294,6 +636,16 @@ extern "C" int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, lon
     return NEAT_OK;
 }
 
+extern "C" int neat_recall_owner_topk(const int32_t* idx, int R, int K, const int32_t* row_owner, const int32_t* col_owner,
+                                      const int32_t* npos, const int32_t* ks, int nk, float* recall, void* stream) {
+    NEAT_REQUIRE(idx && ks && recall && (row_owner || col_owner), NEAT_ERR_ARG, "neat_recall_owner_topk: null pointer");
+    NEAT_REQUIRE(R > 0 && K >= 1 && nk >= 1, NEAT_ERR_SHAPE, "neat_recall_owner_topk: bad shape R=%d K=%d nk=%d", R, K, nk);
+    hipLaunchKernelGGL(recall_owner_kernel, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, idx, R, K, row_owner,
+                       col_owner, npos, ks, nk, recall);
+    NEAT_LAUNCH_CHECK("neat_recall_owner_topk");
+    return NEAT_OK;
+}
+
 extern "C" int neat_best_positive_rank(const float* scores, long ld_row, long ld_col, const uint8_t* pos, long pld_row,
                                        long pld_col, int R, int Ncol, int32_t* rank, void* stream) {
     NEAT_REQUIRE(scores && pos && rank, NEAT_ERR_ARG, "neat_best_positive_rank: null pointer");
@@ -301,6 +653,17 @@ extern "C" int neat_best_positive_rank(const float* scores, long ld_row, long ld
     hipLaunchKernelGGL(best_positive_rank_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, scores, ld_row, ld_col, pos,
                        pld_row, pld_col, R, Ncol, rank);
     NEAT_LAUNCH_CHECK("neat_best_positive_rank");
+    return NEAT_OK;
+}
+
+extern "C" int neat_best_positive_rank_owner(const float* scores, long ld_row, long ld_col, const int32_t* row_owner,
+                                             const int32_t* col_owner, int R, int Ncol, int32_t* rank, void* stream) {
+    NEAT_REQUIRE(scores && rank && (row_owner || col_owner) && !(row_owner && col_owner), NEAT_ERR_ARG,
+                 "neat_best_positive_rank_owner: pass scores, rank and exactly one owner vector");
+    NEAT_REQUIRE(R > 0 && Ncol > 0, NEAT_ERR_SHAPE, "neat_best_positive_rank_owner: empty matrix");
+    hipLaunchKernelGGL(best_positive_rank_owner_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, scores, ld_row, ld_col,
+                       row_owner, col_owner, R, Ncol, rank);
+    NEAT_LAUNCH_CHECK("neat_best_positive_rank_owner");
     return NEAT_OK;
 }
 

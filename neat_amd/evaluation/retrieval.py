@@ -39,13 +39,43 @@ def median_rank(scores, positive_pairs):
     return float(ranks[(len(ranks) - 1) // 2])
 
 
-def recall_metrics(scores, positive_pairs, recall_k_list=(1, 5, 10), with_median_rank=False):
-    """The recall numbers of evaluate_model_with_similarity (retrieval.py:243-250), one pass per direction and
-    k over the whole matrix, plus (optionally) the two medR entries (:254-255)."""
+def _median_of_ranks(ranks):
+    ranks = sorted(r for r in ranks.cpu().tolist() if r > 0)
+    return float(ranks[(len(ranks) - 1) // 2]) if ranks else float("nan")
+
+
+def recall_metrics(scores, positive_pairs=None, recall_k_list=(1, 5, 10), with_median_rank=False, texts_image_index=None):
+    """The recall numbers of evaluate_model_with_similarity (retrieval.py:243-250) and (optionally) the two medR entries
+    (:254-255).  The reference makes one pass over the score matrix per direction AND per k (six passes, each building a
+    [b, k, N] one-hot); here each direction is ONE top-max(k) pass and every smaller k is a prefix of that list.
+
+    ``texts_image_index`` (caption -> image, what the reference builds ``positive_pairs`` from, :229-240): the positives
+    are then taken from this list and no dense bool matrix is read at all; otherwise ``positive_pairs`` is used."""
+    ks = sorted(int(k) for k in recall_k_list)
+    kmax = ks[-1]
     metrics = {}
-    for k in recall_k_list:
-        metrics[f"image_retrieval_recall@{k}"] = (recall_at_k(scores, positive_pairs, k) > 0).float().mean().item()
-        metrics[f"text_retrieval_recall@{k}"] = (recall_at_k(scores.T, positive_pairs.T, k) > 0).float().mean().item()
+    n_txt, n_img = scores.shape
+    _, idx_t2i = ops.topk_rows(scores, min(kmax, n_img))
+    _, idx_i2t = ops.topk_rows(scores.T, min(kmax, n_txt))
+    if texts_image_index is not None:
+        owner = torch.as_tensor(texts_image_index, device=scores.device).to(torch.int32).contiguous()
+        per_image = torch.bincount(owner.long(), minlength=n_img).to(torch.int32)
+        r_t2i = ops.recall_owner_topk(idx_t2i, ks, row_owner=owner)
+        r_i2t = ops.recall_owner_topk(idx_i2t, ks, col_owner=owner, npos=per_image)
+        for q, k in enumerate(ks):
+            metrics[f"image_retrieval_recall@{k}"] = (r_t2i[q] > 0).float().mean().item()
+            metrics[f"text_retrieval_recall@{k}"] = (r_i2t[q] > 0).float().mean().item()
+        if with_median_rank:
+            metrics["image_retrieval_medR"] = _median_of_ranks(ops.best_positive_rank_owner(scores, row_owner=owner))
+            metrics["text_retrieval_medR"] = _median_of_ranks(ops.best_positive_rank_owner(scores.T, col_owner=owner))
+        return metrics
+    if positive_pairs is None:
+        raise RuntimeError("recall_metrics: pass positive_pairs or texts_image_index")
+    for k in ks:
+        r_t = ops.recall_from_topk(idx_t2i[:, :k].contiguous(), positive_pairs)
+        r_i = ops.recall_from_topk(idx_i2t[:, :k].contiguous(), positive_pairs.T)
+        metrics[f"image_retrieval_recall@{k}"] = (r_t > 0).float().mean().item()
+        metrics[f"text_retrieval_recall@{k}"] = (r_i > 0).float().mean().item()
     if with_median_rank:
         metrics["image_retrieval_medR"] = median_rank(scores, positive_pairs)
         metrics["text_retrieval_medR"] = median_rank(scores.T, positive_pairs.T)
@@ -78,10 +108,7 @@ def evaluate_model(model, dataloader, args, tokenizer, recall_k_list=(1, 5, 10))
     images_emb = torch.cat(img_emb).contiguous()
     texts_emb = torch.cat(txt_emb).contiguous()
     scores = ops.gemm_f32_nt(texts_emb, images_emb)
-    positive_pairs = torch.zeros_like(scores, dtype=torch.bool)
-    positive_pairs[torch.arange(len(scores), device=scores.device),
-                   torch.as_tensor(texts_image_index, device=scores.device)] = True
-    return recall_metrics(scores, positive_pairs, recall_k_list, with_median_rank=True)
+    return recall_metrics(scores, None, recall_k_list, with_median_rank=True, texts_image_index=texts_image_index)
 
 
 def retrieval_eval(model, data, args, scores, tokenizer=None):
@@ -118,7 +145,4 @@ def evaluate_model_with_similarity(dataloader, args, scores, recall_k_list=(1, 5
             for off, texts in enumerate(batch_texts):
                 texts_image_index.extend([start + off] * len(texts))
             start += len(batch[0])
-    positive_pairs = torch.zeros_like(scores, dtype=torch.bool)
-    positive_pairs[torch.arange(len(scores), device=scores.device),
-                   torch.as_tensor(texts_image_index, device=scores.device)] = True
-    return recall_metrics(scores, positive_pairs, recall_k_list, with_median_rank=True)
+    return recall_metrics(scores, None, recall_k_list, with_median_rank=True, texts_image_index=texts_image_index)

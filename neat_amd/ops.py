@@ -511,6 +511,40 @@ def best_positive_rank(scores, positive_pairs):
     return out
 
 
+_KS_TABLES = {}
+
+
+def recall_owner_topk(idx, ks, row_owner=None, col_owner=None, npos=None):
+    """Recall for every cut-off of ``ks`` (ascending ints) from ONE top-K index list idx int32 [R, K]; positives as owner
+    vectors (int32 GPU tensors): row_owner [R] and/or col_owner [Ncol]; npos int32 [R] positives per row (None: 1).
+    Returns fp32 [len(ks), R] -- the values ``recall_at_k`` returns for each k."""
+    R, K = idx.shape
+    ks = tuple(int(k) for k in ks)
+    if list(ks) != sorted(ks) or not ks or ks[0] < 1:
+        raise RuntimeError("recall_owner_topk: cut-offs must be ascending positive ints")
+    key = (idx.device.index, ks)
+    table = _KS_TABLES.get(key)
+    if table is None:
+        table = torch.tensor(ks, dtype=i32).to(idx.device)
+        _KS_TABLES[key] = table
+    out = torch.empty(len(ks), R, dtype=f32, device=idx.device)
+    lib.call("neat_recall_owner_topk", _p(idx, i32, "idx"), R, K, _p(row_owner, i32, "row_owner"),
+             _p(col_owner, i32, "col_owner"), _p(npos, i32, "npos"), _p(table), len(ks), _p(out), _stream())
+    return out
+
+
+def best_positive_rank_owner(scores, row_owner=None, col_owner=None):
+    """int32 [R]: 1-based rank of the best-ranked positive per row, positives as ONE owner vector (see recall_owner_topk)."""
+    if not scores.is_cuda or scores.dtype != f32:
+        raise RuntimeError("best_positive_rank_owner: expected float32 scores on the GPU")
+    R, N = scores.shape
+    sr, sc = scores.stride()
+    out = torch.empty(R, dtype=i32, device=scores.device)
+    lib.call("neat_best_positive_rank_owner", scores.data_ptr(), sr, sc, _p(row_owner, i32, "row_owner"),
+             _p(col_owner, i32, "col_owner"), R, N, _p(out), _stream())
+    return out
+
+
 def mcq_scores(image_features, text_features):
     """image_features f32 [B,D], text_features f32 [n,B,D] -> (logits [B,n], pred int32 [B])."""
     n, B, D = text_features.shape

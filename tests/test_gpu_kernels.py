@@ -505,6 +505,67 @@ def test_topk_and_recall_golden():
     np.testing.assert_array_equal(R.batchify(R.recall_at_k, scores, pos, 64, DEV, k=5).numpy(), z["t2i_5"])
 
 
+def test_recall_from_owner_vectors_equals_dense_and_golden():
+    """One top-10 pass per direction + owner vectors (caption -> image) must reproduce the reference's recall@{1,5,10}
+    values row by row (tests/golden/recall.npz), the dense-matrix kernels, and the oracle's metrics."""
+    from neat_amd.evaluation import retrieval as R
+    z = load_golden("recall")
+    scores = torch.from_numpy(z["scores"]).to(DEV)
+    owner = torch.from_numpy(z["owner"]).to(DEV)                         # int32 [n_txt]
+    n_txt, n_img = scores.shape
+    pos = torch.zeros(scores.shape, dtype=torch.bool)
+    pos[torch.arange(n_txt), owner.cpu().long()] = True
+    ks = (1, 5, 10)
+    _, i_t = ops.topk_rows(scores, 10)
+    _, i_i = ops.topk_rows(scores.T, 10)
+    per_image = torch.bincount(owner.long(), minlength=n_img).to(torch.int32)
+    r_t = ops.recall_owner_topk(i_t, ks, row_owner=owner)
+    r_i = ops.recall_owner_topk(i_i, ks, col_owner=owner, npos=per_image)
+    for q, k in enumerate(ks):
+        np.testing.assert_array_equal(r_t[q].cpu().numpy(), z[f"t2i_{k}"])
+        np.testing.assert_array_equal(r_i[q].cpu().numpy(), z[f"i2t_{k}"])
+    m_owner = R.recall_metrics(scores, None, ks, with_median_rank=True, texts_image_index=z["owner"])
+    m_dense = R.recall_metrics(scores, pos.to(DEV), ks, with_median_rank=True)
+    m_orc = O.recall_metrics(scores.cpu(), pos, ks)
+    assert m_owner == m_dense
+    for k_, v in m_orc.items():
+        assert m_owner[k_] == pytest.approx(v, abs=1e-7)
+    assert m_owner["image_retrieval_medR"] == float(z["medr_t2i"]) and m_owner["text_retrieval_medR"] == float(z["medr_i2t"])
+    # ranks, owner form == dense form, also on a matrix full of ties and with images that own no caption
+    tie = torch.from_numpy(z["tie_scores"]).to(DEV)                      # [64, 50]
+    own_t = torch.randint(0, 40, (64,), generator=g(1)).to(torch.int32).to(DEV)        # images 40..49 own nothing
+    pt = torch.zeros(64, 50, dtype=torch.bool)
+    pt[torch.arange(64), own_t.cpu().long()] = True
+    pt = pt.to(DEV)
+    assert torch.equal(ops.best_positive_rank_owner(tie, row_owner=own_t), ops.best_positive_rank(tie, pt))
+    assert torch.equal(ops.best_positive_rank_owner(tie.T, col_owner=own_t), ops.best_positive_rank(tie.T, pt.T))
+    assert (ops.best_positive_rank_owner(tie.T, col_owner=own_t)[40:] == 0).all()
+    for k in (3, 10):
+        _, it = ops.topk_rows(tie.T, k)
+        a = ops.recall_owner_topk(it, (k,), col_owner=own_t, npos=torch.bincount(own_t.long(), minlength=50).to(torch.int32))[0]
+        b = ops.recall_from_topk(it, pt.T)
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))      # 0/0 -> NaN on both paths
+
+
+def test_topk_vector_loads_and_unaligned_rows():
+    """The row kernel reads 16 B per lane when rows are 16-B aligned: column counts that are not a multiple of 4, views
+    with a row pitch, unaligned bases and pitches (4-B fallback) must all give the oracle's indices."""
+    base = torch.randn(37, 1031, generator=g(12))
+    base[:, 500:520] = base[:, 0:20]                     # exact ties across distant columns
+    d = base.to(DEV)
+    for view_h, view_d in ((base[:, :1028], d[:, :1028]), (base[:, :1027], d[:, :1027]), (base[:, 1:1030], d[:, 1:1030]),
+                           (base[:, :5], d[:, :5]), (base[:, 4:263], d[:, 4:263])):
+        for k in (1, 5, 10):
+            if k > view_h.shape[1]:
+                continue
+            val, idx = ops.topk_rows(view_d, k)
+            rv, ri = O.topk_rows(view_h.contiguous(), k)
+            assert torch.equal(idx.cpu().long(), ri) and torch.equal(val.cpu(), rv), (tuple(view_h.shape), k)
+    odd = torch.randn(9, 1030, generator=g(13))          # pitch 1030: rows are not 16-B aligned -> 4-B loads
+    _, idx = ops.topk_rows(odd.to(DEV), 10)
+    assert torch.equal(idx.cpu().long(), O.topk_rows(odd, 10)[1])
+
+
 def test_topk_ties_lowest_index_first():
     z = load_golden("recall")
     tie = torch.from_numpy(z["tie_scores"])

@@ -12,5 +12,10 @@ done
 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_auto.txt
 NEAT_GEMM=panel timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_panel.txt
 NEAT_GEMM=t256 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_t256.txt
-rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# retrieval scoring at config-2 size: per-kernel time and FETCH_SIZE of the top-k passes (25 014 x 5 000, both directions)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tk -- python3 tools/topk_bench.py > $O/topk_bench.txt 2>&1 || exit 1
+cp $(ls $O/tk/*/*kernel_stats.csv | head -1) $O/topk_kernel_stats.csv
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_tk -- python3 tools/topk_bench.py > $O/pmc_tk.log 2>&1 || exit 1
+python3 tools/summarize_pmc.py $(ls $O/pmc_tk/*/*counter_collection.csv | head -1) $O/topk_pmc_fetch_size.csv || exit 1
+rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/tk $O/pmc_tk
 head -8 $O/bench_kernel_stats.csv | cut -c1-160; head -6 $O/bench_pmc_fetch_size.csv | cut -c1-200; head -6 $O/bench_pmc_write_size.csv | cut -c1-200
