@@ -143,6 +143,102 @@ __global__ __launch_bounds__(256) void topk_rows_fast_kernel(const float* __rest
     }
 }
 
+// Register-resident fast tier for rows of up to 64 * 4 * NV columns (NV <= 20: 5 120 columns, 16-B aligned rows).  The
+// insertion lists above are issue-bound: some lane of the wave passes its list threshold at almost every step and then
+// the whole wave walks the insertion code, and every merge round is a chain of dependent cross-lane shuffles (136 us for
+// 25 014 x 5 000 = 3.7 TB/s, where a plain streaming read reaches 6.3 TB/s on the same GPU).  Here a wave loads its WHOLE
+// row into registers first (NV non-temporal 16-B loads per lane, all in flight at once) and selects without a single
+// shuffle:
+//   1. every lane takes the maximum of its own elements (one v_max per element);
+//   2. T = the k-th largest of the 64 lane maxima, found bit by bit on an order-preserving integer key (32 ballots +
+//      scalar pop-counts): k lanes hold an element >= T, so the k-th largest element of the row is >= T;
+//   3. the elements >= T (typically 10..25) are compacted into an LDS list (ballot + prefix count; a 16-B vector without
+//      a candidate costs one compare and one uniform branch);
+//   4. with at most 64 candidates, one per lane, every lane counts the candidates that beat its own (value descending,
+//      lowest column first on ties) by v_readlane broadcasts; that count is the candidate's place in the output.
+// The result is exact.  A row with more than 64 candidates (heavy ties) or fewer than k finite values is flagged for the
+// exact tier.
+constexpr int REG_CAP = 64;
+
+__device__ __forceinline__ uint32_t order_key(float x) {                  // a < b  <=>  key(a) < key(b) (no NaN)
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restrict__ scores, long ld_row, int R, int Ncol,
+                                                            int k, int32_t* __restrict__ idx, float* __restrict__ val,
+                                                            int* __restrict__ need) {
+    __shared__ float cv[4][REG_CAP];
+    __shared__ int ci[4][REG_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = Ncol >> 2, rem = Ncol & 3;
+    float* wcv = cv[wave];
+    int* wci = ci[wave];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float* row = scores + (long)r * ld_row;
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+        f32x4 x[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int g = lane + 64 * j;
+            x[j] = g < nvec ? __builtin_nontemporal_load(row4 + g) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        const float xt = lane < rem ? row[(nvec << 2) + lane] : -INFINITY;   // the last Ncol % 4 columns
+        float m = xt;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) m = fmaxf(m, fmaxf(fmaxf(x[j][0], x[j][1]), fmaxf(x[j][2], x[j][3])));
+        // k-th largest lane maximum, MSB first: t grows by a bit whenever at least k lanes stay at or above it
+        const uint32_t mk = order_key(m);
+        uint32_t t = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t c = t | (1u << b);
+            if (__popcll(__ballot(mk >= c)) >= k) t = c;
+        }
+        const float T = __uint_as_float((t & 0x80000000u) ? (t & 0x7fffffffu) : ~t);
+        int base = 0;                                                     // wave-uniform candidate count
+        auto push = [&](float v, int col) {
+            const bool p = v >= T;
+            const unsigned long long b = __ballot(p);
+            if (b) {
+                const int pos = base + __popcll(b & lt_mask);
+                if (p && pos < REG_CAP) { wcv[pos] = v; wci[pos] = col; }
+                base += __popcll(b);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float m4 = fmaxf(fmaxf(x[j][0], x[j][1]), fmaxf(x[j][2], x[j][3]));
+            if (__ballot(m4 >= T)) {
+                const int c0 = (lane + 64 * j) << 2;
+                push(x[j][0], c0); push(x[j][1], c0 + 1); push(x[j][2], c0 + 2); push(x[j][3], c0 + 3);
+            }
+        }
+        if (rem) push(xt, (nvec << 2) + lane);
+        const bool ok = base <= REG_CAP && base >= k && T > -INFINITY;    // wave-uniform
+        if (ok) {
+            // one candidate per lane; place = number of candidates that come before it
+            const bool have = lane < base;
+            const float v = have ? wcv[lane] : -INFINITY;
+            const int c = have ? wci[lane] : IMAX;
+            const uint32_t kv = order_key(v);
+            int place = 0;
+            for (int i = 0; i < base; ++i) {
+                const uint32_t ov = __builtin_amdgcn_readlane(kv, i);
+                const int oc = __builtin_amdgcn_readlane(c, i);
+                place += (ov > kv || (ov == kv && oc < c)) ? 1 : 0;
+            }
+            if (have && place < k) {
+                idx[(long)r * k + place] = c;
+                if (val) val[(long)r * k + place] = v;
+            }
+        }
+        if (lane == 0) need[r] = ok ? 0 : 1;
+    }
+}
+
 // The exact kernels (a k-entry list per lane).  need == NULL: every row; else only rows with need[r] != 0.
 // One 256-thread block per row whatever the layout (with ld_col != 1, a transposed view, a lane's loads are strided -- slow
 // per element, but this tier only sees the rows the fast tier flagged): a k-entry list per lane, then k rounds of a
@@ -596,9 +692,19 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
     const int xgrid = R > 16384 ? 16384 : R;                          // exact tier: a block per row
     if (ld_col == 1) {
         const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_row % 4 == 0);
-        if (vec) hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, true>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
+        const int nv = cdiv(Ncol >> 2, 64);                               // 16-B loads per lane that hold a whole row
+        const bool reg = vec && nv <= 20;                           // NV = 24 would need all 256 VGPRs
+        if (reg) {
+#define TOPK_REG(NVV) hipLaunchKernelGGL((topk_rows_reg_kernel<NVV>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need)
+            if (nv <= 4) TOPK_REG(4);
+            else if (nv <= 8) TOPK_REG(8);
+            else if (nv <= 12) TOPK_REG(12);
+            else if (nv <= 16) TOPK_REG(16);
+            else TOPK_REG(20);
+#undef TOPK_REG
+        } else if (vec) hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, true>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
         else hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, false>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
-        if (k > SHORT_M) {
+        if (k > SHORT_M || reg) {
             if (vec) {
                 TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, true>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, 1L, R, Ncol, k, idx, val, w.need));
             } else {
@@ -674,5 +780,46 @@ extern "C" int neat_mcq_scores(const float* img, const float* txt, float* logits
     hipLaunchKernelGGL(mcq_scores_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, img, txt, logits, pred, B,
                        nopt, D);
     NEAT_LAUNCH_CHECK("neat_mcq_scores");
+    return NEAT_OK;
+}
+
+// ---- fused similarity + top-k: the offline path's `texts_emb @ images_emb.t()` (evaluation/retrieval.py:70) followed by
+// torch.topk (:294-300), without the [Nq, Ng] score matrix in HBM.  The scores are produced SIM_CHUNK-bounded row chunks at
+// a time by the exact-fp32 MFMA GEMM into the caller's workspace and reduced by the row kernels above before the next
+// chunk overwrites them: a chunk (<= 64 MiB) stays in the 256 MiB Infinity Cache between its producer and its consumer,
+// so HBM sees Q and G once per chunk and the k winners, not 2 x Nq x Ng x 4 bytes.  Bit-identical to
+// neat_gemm_f32_nt + neat_topk_rows (same kernels, same order of operations).
+extern "C" int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+
+static inline int sim_chunk_rows(int Nq, int Ng) {
+    long rows = (64L << 20) / (4L * Ng);
+    rows = rows / 128 * 128;
+    if (rows < 128) rows = 128;
+    return (int)(rows < Nq ? rows : Nq);
+}
+
+extern "C" long neat_sim_topk_ws_bytes(int Nq, int Ng, int k) {
+    if (Nq <= 0 || Ng <= 0 || k < 1) return 256;
+    const int ch = sim_chunk_rows(Nq, Ng);
+    const long sc = ((long)ch * Ng * 4 + 255) / 256 * 256;
+    return sc + neat_topk_ws_bytes(ch, Ng, k);
+}
+
+extern "C" int neat_sim_topk(const float* Q, const float* G, int k, int32_t* idx_out, float* val_out, int Nq, int Ng, int D,
+                             void* ws, void* stream) {
+    NEAT_REQUIRE(Q && G && idx_out && ws, NEAT_ERR_ARG, "neat_sim_topk: null pointer");
+    NEAT_REQUIRE((uintptr_t)ws % 256 == 0, NEAT_ERR_ARG, "neat_sim_topk: workspace not 256-B aligned");
+    NEAT_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 16 == 0 && k >= 1 && k <= 32 && k <= Ng, NEAT_ERR_SHAPE,
+                 "neat_sim_topk: Nq=%d Ng=%d D=%d k=%d (need D %% 16 == 0, 1 <= k <= min(32, Ng))", Nq, Ng, D, k);
+    const int ch = sim_chunk_rows(Nq, Ng);
+    float* sc = reinterpret_cast<float*>(ws);
+    void* tws = reinterpret_cast<char*>(ws) + ((long)ch * Ng * 4 + 255) / 256 * 256;
+    for (int q0 = 0; q0 < Nq; q0 += ch) {
+        const int rows = Nq - q0 < ch ? Nq - q0 : ch;
+        if (int rc = neat_gemm_f32_nt(Q + (long)q0 * D, G, sc, rows, Ng, D, stream)) return rc;
+        if (int rc = neat_topk_rows(sc, Ng, 1, rows, Ng, k, idx_out + (long)q0 * k, val_out ? val_out + (long)q0 * k : nullptr,
+                                    tws, stream))
+            return rc;
+    }
     return NEAT_OK;
 }

@@ -82,6 +82,26 @@ def recall_metrics(scores, positive_pairs=None, recall_k_list=(1, 5, 10), with_m
     return metrics
 
 
+def recall_from_embeddings(texts_emb, images_emb, texts_image_index, recall_k_list=(1, 5, 10)):
+    """The recall entries of ``evaluate_model`` (retrieval.py:70 + :243-250) straight from the embeddings, without the
+    [N_text, N_image] score matrix in HBM: one fused similarity + top-k call per direction (``neat_sim_topk``; the scores
+    only exist in a cache-sized chunk) and the owner-vector recall.  Same numbers as ``recall_metrics`` on the
+    materialised matrix (same kernels, bit-identical lists); medR needs whole score rows and is not produced here."""
+    ks = sorted(int(k) for k in recall_k_list)
+    n_txt, n_img = texts_emb.shape[0], images_emb.shape[0]
+    owner = torch.as_tensor(texts_image_index, device=texts_emb.device).to(torch.int32).contiguous()
+    per_image = torch.bincount(owner.long(), minlength=n_img).to(torch.int32)
+    _, idx_t2i = ops.sim_topk(texts_emb, images_emb, min(ks[-1], n_img))
+    _, idx_i2t = ops.sim_topk(images_emb, texts_emb, min(ks[-1], n_txt))
+    r_t2i = ops.recall_owner_topk(idx_t2i, ks, row_owner=owner)
+    r_i2t = ops.recall_owner_topk(idx_i2t, ks, col_owner=owner, npos=per_image)
+    metrics = {}
+    for q, k in enumerate(ks):
+        metrics[f"image_retrieval_recall@{k}"] = (r_t2i[q] > 0).float().mean().item()
+        metrics[f"text_retrieval_recall@{k}"] = (r_i2t[q] > 0).float().mean().item()
+    return metrics
+
+
 def dataloader_with_indices(dataloader):
     """retrieval.py:259-278"""
     start = 0

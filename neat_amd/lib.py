@@ -61,6 +61,8 @@ SIGNATURES = {
     "neat_best_positive_rank_owner": (_I, [_P, _L, _L, _P, _P, _I, _I, _P, _P]),
     "neat_mcq_scores": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "neat_gemm_f32_nt": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "neat_sim_topk_ws_bytes": (_L, [_I, _I, _I]),
+    "neat_sim_topk": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "neat_cast_bf16": (_I, [_P, _P, _L, _P]),
     "neat_transpose_cast_bf16": (_I, [_P, _P, _I, _I, _P]),
 }

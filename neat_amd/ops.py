@@ -483,6 +483,20 @@ def topk_rows(scores, k) -> Tuple[torch.Tensor, torch.Tensor]:
     return val, idx
 
 
+def sim_topk(Q, G, k) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k rows of G for every row of Q by exact-fp32 dot product (values, int32 indices), without the [Nq, Ng] score
+    matrix in HBM (reference evaluation/retrieval.py:70 + :294-300).  Bit-identical to gemm_f32_nt + topk_rows."""
+    Nq, D = Q.shape
+    Ng = G.shape[0]
+    if G.shape[1] != D:
+        raise RuntimeError(f"sim_topk: feature sizes differ ({tuple(Q.shape)} vs {tuple(G.shape)})")
+    idx = torch.empty(Nq, k, dtype=i32, device=Q.device)
+    val = torch.empty(Nq, k, dtype=f32, device=Q.device)
+    ws = torch.empty(lib.load().neat_sim_topk_ws_bytes(Nq, Ng, k), dtype=torch.uint8, device=Q.device)
+    lib.call("neat_sim_topk", _p(Q, f32, "Q"), _p(G, f32, "G"), k, _p(idx), _p(val), Nq, Ng, D, _p(ws), _stream())
+    return val, idx
+
+
 def recall_from_topk(idx, positive_pairs):
     if positive_pairs.dtype == torch.bool:
         positive_pairs = positive_pairs.view(torch.uint8)

@@ -566,6 +566,65 @@ def test_topk_vector_loads_and_unaligned_rows():
     assert torch.equal(idx.cpu().long(), O.topk_rows(odd, 10)[1])
 
 
+def test_topk_register_resident_rows():
+    """Rows of up to 5 120 columns are selected from registers (threshold from the lane maxima, candidates through LDS):
+    every template width, planted ties, a row full of equal values (more candidates than the LDS list holds -> the exact
+    tier redoes it), rows with -inf entries and a row of only -inf, against the oracle's indices and values."""
+    for n, seed in ((200, 21), (1028, 22), (2050, 23), (3100, 24), (4099, 25), (5000, 26), (5120, 27)):
+        m = torch.randn(9, n, generator=g(seed))
+        m[1, n // 2: n // 2 + 40] = m[1, :40]                      # exact ties across distant columns
+        m[2] = 0.25                                                # all equal: lowest indices win
+        m[3, ::3] = float("-inf")
+        m[4] = float("-inf")
+        m[4, 5] = 1.0                                              # fewer finite values than k
+        m[5, :] = torch.round(m[5] * 2) / 2                        # a few hundred ties per value
+        m[6, -3:] = 9.0                                            # winners in the last (Ncol % 4) columns
+        d = m.to(DEV)
+        for k in (1, 4, 10, 32):
+            val, idx = ops.topk_rows(d, k)
+            rv, ri = O.topk_rows(m, k)
+            finite = torch.isfinite(rv)
+            assert torch.equal(val.cpu(), rv), (n, k)
+            assert torch.equal(idx.cpu().long()[finite], ri[finite]), (n, k)
+
+
+def test_sim_topk_equals_gemm_then_topk():
+    """neat_sim_topk (scores only ever in a cache-sized workspace chunk) against the materialised path, bit for bit:
+    several chunks with a ragged last one (4 000 queries x 5 000 gallery rows: chunks of 3 328), both directions, planted
+    duplicate gallery rows (exact ties), and the oracle's indices on a small case."""
+    gen = g(31)
+    Q = torch.nn.functional.normalize(torch.randn(4000, 64, generator=gen), dim=-1)
+    G = torch.nn.functional.normalize(torch.randn(5000, 64, generator=gen), dim=-1)
+    G[4000:4050] = G[100:150]                                     # duplicate rows: equal scores, lowest index first
+    q, gd = Q.to(DEV), G.to(DEV)
+    for a, b in ((q, gd), (gd, q)):
+        S = ops.gemm_f32_nt(a, b)
+        for k in (1, 10):
+            v0, i0 = ops.topk_rows(S, k)
+            v1, i1 = ops.sim_topk(a, b, k)
+            assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    Qs, Gs = Q[:37].contiguous(), G[3990:4060].contiguous()
+    v, i = ops.sim_topk(Qs.to(DEV), Gs.to(DEV), 5)
+    S_ref = O.similarity(Qs, Gs) if hasattr(O, "similarity") else None
+    if S_ref is not None:
+        assert torch.equal(i.cpu().long(), O.topk_rows(S_ref, 5)[1])
+    else:
+        Sg = ops.gemm_f32_nt(Qs.to(DEV), Gs.to(DEV)).cpu()
+        assert torch.equal(i.cpu().long(), O.topk_rows(Sg, 5)[1])
+
+
+def test_recall_from_embeddings_equals_materialised_scores():
+    from neat_amd.evaluation import retrieval as R
+    gen = g(32)
+    T = torch.nn.functional.normalize(torch.randn(1003, 64, generator=gen), dim=-1).to(DEV)
+    I = torch.nn.functional.normalize(torch.randn(211, 64, generator=gen), dim=-1).to(DEV)
+    owner = (torch.arange(1003) // 5).clamp_max(210)
+    I[owner[::7]] = (I[owner[::7]] + 0.5 * T[::7])                # some captions do retrieve their image
+    a = R.recall_from_embeddings(T, I, owner)
+    b = R.recall_metrics(ops.gemm_f32_nt(T, I), None, (1, 5, 10), texts_image_index=owner)
+    assert a == b and a["image_retrieval_recall@10"] > 0.05
+
+
 def test_topk_ties_lowest_index_first():
     z = load_golden("recall")
     tie = torch.from_numpy(z["tie_scores"])

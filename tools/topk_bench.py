@@ -38,6 +38,10 @@ us, (_, it) = timed(lambda: ops.topk_rows(scores, 10))
 print(f"top-10 rows  (t2i, {NT} rows x {NI}):      {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s of 8 = {byts / us / 8e6:.3f}")
 us, (_, ii) = timed(lambda: ops.topk_rows(scores.T, 10))
 print(f"top-10 cols  (i2t, {NI} rows x {NT}, view): {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s of 8 = {byts / us / 8e6:.3f}")
+us, _ = timed(lambda: ops.sim_topk(txt, img, 10), 3)
+print(f"fused similarity + top-10 (t2i, scores never in HBM as a whole):        {us:9.1f} us")
+us, _ = timed(lambda: ops.sim_topk(img, txt, 10), 3)
+print(f"fused similarity + top-10 (i2t, gallery = the captions):                {us:9.1f} us")
 per_image = torch.bincount(owner.long(), minlength=NI).to(torch.int32)
 us, _ = timed(lambda: (ops.recall_owner_topk(it, (1, 5, 10), row_owner=owner),
                        ops.recall_owner_topk(ii, (1, 5, 10), col_owner=owner, npos=per_image)))
