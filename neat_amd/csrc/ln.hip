@@ -11,6 +11,22 @@
 #include "common.h"
 
 namespace neat {
+// streaming accesses: the residual stream and its gradient are read once here and next touched a whole layer later, so they
+// are loaded / stored non-temporally (measured on MI355X: a pure streaming read reaches 7.0 TB/s with non-temporal loads
+// against 6.3 TB/s without, tools/read_probe.hip); LN outputs that the next GEMM reads at once keep the default policy
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ uint2 ld_nt(const uint2* p) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    return make_uint2(t[0], t[1]);
+}
+__device__ __forceinline__ void st_nt(float4* p, float4 v) {
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+}
+
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / WAVE;
@@ -47,7 +63,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
         for (int i = 0; i < NCH; ++i) {
             int c = lane + 64 * i;
             if (c < nch) {
-                v[i] = xr[c];
+                v[i] = ld_nt(xr + c);
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
         }
@@ -111,8 +127,8 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         for (int i = 0; i < NCH; ++i) {
             int c = lane + 64 * i;
             if (c < nch) {
-                float4 xv = xr[c];
-                uint2 d = dyr[c];
+                float4 xv = ld_nt(xr + c);
+                uint2 d = ld_nt(dyr + c);
                 float d0 = __uint_as_float(d.x << 16), d1 = __uint_as_float(d.x & 0xffff0000u);
                 float d2 = __uint_as_float(d.y << 16), d3 = __uint_as_float(d.y & 0xffff0000u);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
@@ -135,10 +151,10 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
                 o.z = rs * (gg[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (gg[i].w - m1 - xh[i].w * m2);
                 if (dres) {
-                    float4 r = reinterpret_cast<const float4*>(dres + row * cols)[c];
+                    float4 r = ld_nt(reinterpret_cast<const float4*>(dres + row * cols) + c);
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                 }
-                if (dxf) reinterpret_cast<float4*>(dxf + row * cols)[c] = o;
+                if (dxf) st_nt(reinterpret_cast<float4*>(dxf + row * cols) + c, o);
                 if (dxb) reinterpret_cast<uint2*>(dxb + row * cols)[c] = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
             }
         }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneat_hip.so")
+# NEAT_HIP_LIB: an alternative build of the same library (kernel A/B experiments from tools/); default: the in-tree build
+LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "libneat_hip.so")
 
 EPI_BF16, EPI_BIAS_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_F32 = range(6)
 
