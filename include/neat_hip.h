@@ -27,7 +27,7 @@ enum {
     NEAT_ERR_SHAPE = -1,       /* shape / alignment not supported by the kernel */
     NEAT_ERR_ARG = -2,         /* null pointer or invalid enum */
     NEAT_ERR_HIP = -3,         /* HIP runtime error at launch */
-    NEAT_ERR_COMM = -4         /* collective error */
+    NEAT_ERR_COMM = -4         /* collective error: RCCL missing, no communicator, or an RCCL call failed (neat_comm_*) */
 };
 
 /* GEMM epilogues (neat_gemm_bf16) */
@@ -260,6 +260,28 @@ int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int
 long neat_sim_topk_ws_bytes(int Nq, int Ng, int k);
 int neat_sim_topk(const float* Q, const float* G, int k, int32_t* idx_out, float* val_out, int Nq, int Ng, int D,
                   void* ws, void* stream);
+
+/* ---- collectives of the data-parallel step, one RCCL communicator per process (= per GPU).  Stand in
+ * for the reference's torch.distributed helpers (src/ddp.py:6-70: all_gather of features, gradients summed over ranks)
+ * for callers that bind this library without torch.distributed.  RCCL is resolved at run time (dlopen): the library
+ * loads without it and these calls then return NEAT_ERR_COMM.
+ *   neat_comm_unique_id : rank 0 fills id (NEAT_COMM_ID_BYTES bytes) and hands it to the other ranks out of band
+ *                         (file, socket, MPI, a torch.distributed broadcast ...)
+ *   neat_comm_init      : every rank, with its GPU current (hipSetDevice), the same id, world size and its rank; blocks
+ *                         until all ranks have called it
+ *   neat_comm_allgather : recv[r*bytes .. (r+1)*bytes) = rank r's send[0 .. bytes)  (device pointers, same bytes on every
+ *                         rank; used for the [text | coarse] feature shards and the gallery embeddings)
+ *   neat_comm_allreduce_f32 : recv = sum over ranks of send (n floats, in place allowed; the flat LN-gradient buffer)
+ *   neat_comm_destroy   : frees the communicator (no-op without one)
+ * All collectives are enqueued on `stream` and do not synchronise the host. */
+#define NEAT_COMM_ID_BYTES 128
+int neat_comm_unique_id(void* id);
+int neat_comm_init(const void* id, int world, int rank);
+int neat_comm_world(void);
+int neat_comm_rank(void);
+int neat_comm_allgather(const void* send, void* recv, long bytes, void* stream);
+int neat_comm_allreduce_f32(const float* send, float* recv, long n, void* stream);
+int neat_comm_destroy(void);
 
 /* f32 -> bf16 cast (weights at load time, n elements) */
 int neat_cast_bf16(const float* src, uint16_t* dst, long n, void* stream);

@@ -64,6 +64,13 @@ SIGNATURES = {
     "neat_gemm_f32_nt": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "neat_sim_topk_ws_bytes": (_L, [_I, _I, _I]),
     "neat_sim_topk": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "neat_comm_unique_id": (_I, [_P]),
+    "neat_comm_init": (_I, [_P, _I, _I]),
+    "neat_comm_world": (_I, []),
+    "neat_comm_rank": (_I, []),
+    "neat_comm_allgather": (_I, [_P, _P, _L, _P]),
+    "neat_comm_allreduce_f32": (_I, [_P, _P, _L, _P]),
+    "neat_comm_destroy": (_I, []),
     "neat_cast_bf16": (_I, [_P, _P, _L, _P]),
     "neat_transpose_cast_bf16": (_I, [_P, _P, _I, _I, _P]),
 }

@@ -65,9 +65,24 @@ def _host_staged(x) -> bool:
     return x.is_cuda and dist.get_backend() == "gloo"
 
 
+def _own_comm(x) -> bool:
+    """NEAT_COMM=rccl: GPU collectives go through the library's own RCCL communicator (C ABI neat_comm_*), created on
+    first use from the existing process group; everything else (CPU tensors, non-float reductions) stays on
+    torch.distributed."""
+    from . import comm
+    if not (comm.ENABLED and x.is_cuda):
+        return False
+    if not comm.ready():
+        comm.init_from_process_group()
+    return True
+
+
 def _gather_into(out, x):
     """dist.all_gather_into_tensor(out, x) (rank order along dim 0)."""
-    if _host_staged(x):
+    if _own_comm(x):
+        from . import comm
+        comm.all_gather_into(out, x)
+    elif _host_staged(x):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, x.contiguous().cpu())
         out.copy_(host)
@@ -76,7 +91,10 @@ def _gather_into(out, x):
 
 
 def _reduce_sum(x):
-    if _host_staged(x):
+    if x.dtype == torch.float32 and x.is_contiguous() and _own_comm(x):
+        from . import comm
+        comm.all_reduce_sum_(x)
+    elif _host_staged(x):
         host = x.cpu()
         dist.all_reduce(host)
         x.copy_(host)

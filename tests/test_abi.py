@@ -56,6 +56,18 @@ def test_argument_validation_without_gpu():
     assert rc == -1
 
 
+def test_comm_entry_points_fail_cleanly_without_a_communicator():
+    """neat_comm_*: no communicator -> NEAT_ERR_COMM (-4) with a message, before any RCCL or HIP call."""
+    from neat_amd import lib
+    L = lib.load()
+    assert L.neat_comm_world() == 0 and L.neat_comm_rank() == -1
+    assert L.neat_comm_allreduce_f32(1, 1, 4, None) == -4 and "no communicator" in lib.last_error()
+    assert L.neat_comm_allgather(1, 1, 4, None) == -4
+    assert L.neat_comm_init(None, 1, 0) == -2
+    assert L.neat_comm_destroy() == 0
+    assert L.neat_sim_topk_ws_bytes(25014, 5000, 10) > 64 * 1024 * 1024 // 2
+
+
 def test_product_path_has_no_oracle_import():
     """The shipped package must never import the oracle (parity claims depend on it)."""
     pkg = os.path.join(ROOT, "neat_amd")
