@@ -267,6 +267,18 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_w4_kernel(const bf16_t* __r
             staged_prev = do_stage;
             pb = (pb + 1) & 3;
         }
+#ifdef W4_NOPARK
+        {   // main loop only (timing experiment): keep the accumulators alive, store nothing
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sink += acc[i][t][0] + acc[i][t][15];
+            if (sink == 1234.5f) out0[threadIdx.x] = 0;
+            if (tu + 1 < U) unit_of(tu + 1, c_row0, c_cb);
+            continue;
+        }
+#endif
         // the unit is complete: park it as bf16 (what was parked from the unit before has been stored by now)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -284,8 +296,10 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_w4_kernel(const bf16_t* __r
         if (tu + 1 < U) unit_of(tu + 1, c_row0, c_cb);
     }
     // the last unit's tile
+#ifndef W4_NOPARK
 #pragma unroll
     for (int pcs = 0; pcs < 32; ++pcs) drip(pcs >> 3, (pcs >> 1) & 3, pcs & 1);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -369,8 +383,10 @@ static void bench(int M, int N, int K, int epi, const char* name) {
 
 int main() {
     int bad = 0;
+#ifndef W4_NOPARK
     bad |= check(768, 512, 256, EPI_BF16);
     bad |= check(1024, 1024, 512, EPI_BIAS_GELU);
+#endif
     if (bad) { printf("FAILED\n"); return 1; }
     bench(78848, 2048, 512, EPI_BIAS_GELU, "c_fc  BIAS_GELU");
     bench(78848, 1536, 512, EPI_BF16, "qkv   (BF16 epi)");
