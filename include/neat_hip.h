@@ -127,7 +127,13 @@ int neat_frames_preprocess(const uint8_t* src, int T, int H, int W, float* dst, 
  * lse f32 [nseq, heads, L] (log-sum-exp of the scaled scores, saved for backward; may be NULL).
  * cu_seqlens == NULL: fixed-length batch, rows = nseq*L, sequence s owns rows s*L .. s*L+L-1.
  * cu_seqlens i32 [nseq+1] (packed batch, see neat_pack_plan): sequence s owns rows cu[s] .. cu[s+1]-1, L is the
- * maximum length (<= 80) and the row pitch of lse. */
+ * maximum length (<= 80) and the row pitch of lse.
+ * causal: bit 0 = causal mask (NEAT_ATTN_CAUSAL); bit 1 = head-major qkv / dqkv columns (NEAT_ATTN_HEAD_MAJOR): per token
+ * [head][q | k | v][64] instead of the nn.MultiheadAttention order [q | k | v][head][64], i.e. the in_proj weight rows
+ * permuted once before packing -- a head's three pieces are then one 384-B run per token (attention 8 % faster); out /
+ * dout keep the [rows, C] order either way. */
+#define NEAT_ATTN_CAUSAL 1
+#define NEAT_ATTN_HEAD_MAJOR 2
 int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu_seqlens, int nseq, int L,
                   int heads, int causal, void* stream);
 /* dout bf16 [rows, C] -> dqkv bf16 [rows, 3*C]; L <= 80 */

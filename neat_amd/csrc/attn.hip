@@ -69,7 +69,8 @@ __device__ __forceinline__ float xor_sum_16_32(float v) {
 template <int NT>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                               bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                              int nseq, int L, int heads, int causal) {
+                                                              int nseq, int L, int heads, int flags) {
+    const int causal = flags & 1;
     constexpr int LP = NT * 16;
     constexpr int LDT = LP + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,9 +83,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const bf16_t* __re
     const bool live = item < total;
     if (!live) item = total - 1;
     const int s = item / heads, h = item - s * heads;
-    const bf16_t* qb = qkv + (long)s * L * ld + h * HD;
-    const bf16_t* kb = qb + C;
-    const bf16_t* vb = qb + 2 * C;
+    const int part = (flags & 2) ? HD : C;                      // distance between the q, k and v pieces of one head
+    const bf16_t* qb = qkv + (long)s * L * ld + ((flags & 2) ? 3 * h * HD : h * HD);
+    const bf16_t* kb = qb + part;
+    const bf16_t* vb = qb + 2 * part;
     bf16_t* Vt = reinterpret_cast<bf16_t*>(smem) + (long)wave * HD * LDT;
     stage_transposed(vb, ld, L, LP, Vt, LDT, lane);
     __syncthreads();
@@ -194,7 +196,7 @@ __device__ __forceinline__ int snake_owner(int rank) {
 // pitch AB_PITCH.  U independent 16-B loads per thread are issued before the first LDS store, so that a
 // workgroup has its whole tile set in flight at once (rows >= L are zero-filled).
 template <int NW, int U, int LP>
-__device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long ld, int C, const bf16_t* dob, int L) {
+__device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long ld, int part, const bf16_t* dob, int dld, int L) {
     constexpr int total = LP * 8 * NW;
     for (int base = 0; base < total; base += U * AB_THREADS) {
         uint4 v[U];
@@ -206,8 +208,8 @@ __device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long 
             const int row = rem >> 3, ch = rem & 7;
             v[u] = make_uint4(0, 0, 0, 0);
             if (idx < total && row < L)
-                v[u] = which < 3 ? *reinterpret_cast<const uint4*>(qb + (long)row * ld + which * C + ch * 8)
-                                 : *reinterpret_cast<const uint4*>(dob + (long)row * C + ch * 8);
+                v[u] = which < 3 ? *reinterpret_cast<const uint4*>(qb + (long)row * ld + which * part + ch * 8)
+                                 : *reinterpret_cast<const uint4*>(dob + (long)row * dld + ch * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -228,7 +230,8 @@ template <int NT>
 __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv,
                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
                                                                const int32_t* __restrict__ cu, int nseq, int Lmax,
-                                                               int heads, int causal) {
+                                                               int heads, int flags) {
+    const int causal = flags & 1;
     constexpr int LP = NT * 16;
     constexpr int NP = (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,9 +247,10 @@ __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __r
     // packed batches: rows cu[s] .. cu[s+1]-1; fixed-length batches: rows s*Lmax .. s*Lmax+Lmax-1
     const long r0 = cu ? (long)cu[s] : (long)s * Lmax;
     const int L = cu ? cu[s + 1] - cu[s] : Lmax;
-    const bf16_t* qb = qkv + r0 * ld + h * HD;
+    const int part = (flags & 2) ? HD : C;                      // head-major qkv: [row][head][q|k|v][64]
+    const bf16_t* qb = qkv + r0 * ld + ((flags & 2) ? 3 * h * HD : h * HD);
 
-    stage_tiles<3, (LP * 8 * 3 + AB_THREADS - 1) / AB_THREADS, LP>(Qs, qb, ld, C, nullptr, L);
+    stage_tiles<3, (LP * 8 * 3 + AB_THREADS - 1) / AB_THREADS, LP>(Qs, qb, ld, part, nullptr, 0, L);
     __syncthreads();
     const float scale = 0.125f;  // 1/sqrt(64)
 
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
                                                               const float* __restrict__ lse,
                                                               bf16_t* __restrict__ dqkv,
                                                               const int32_t* __restrict__ cu, int nseq, int Lmax,
-                                                              int heads, int causal) {
+                                                              int heads, int flags) {
+    const int causal = flags & 1;
     constexpr int LP = NT * 16;
     constexpr int NP = (NT + 1) / 2;  // pairs of 16-wide tiles = MFMA k-steps over a summed sequence index
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,12 +348,14 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
     const int s = blockIdx.x / heads, h = blockIdx.x - s * heads;
     const long r0 = cu ? (long)cu[s] : (long)s * Lmax;
     const int L = cu ? cu[s + 1] - cu[s] : Lmax;
-    const bf16_t* qb = qkv + r0 * ld + h * HD;
+    const int part = (flags & 2) ? HD : C;                      // head-major qkv / dqkv: [row][head][q|k|v][64]
+    const int hoff = (flags & 2) ? 3 * h * HD : h * HD;
+    const bf16_t* qb = qkv + r0 * ld + hoff;
     const bf16_t* dob = dout + r0 * C + h * HD;
     const float* lser = lse + ((long)s * heads + h) * Lmax;
-    bf16_t* dqb = dqkv + r0 * ld + h * HD;
-    bf16_t* dkb = dqb + C;
-    bf16_t* dvb = dqb + 2 * C;
+    bf16_t* dqb = dqkv + r0 * ld + hoff;
+    bf16_t* dkb = dqb + part;
+    bf16_t* dvb = dqb + 2 * part;
 
     // acc[dt] holds T^T[d = dt*16 + 4fq + r][row = fr] of a 16-row result tile starting at sequence row r0
     auto store_tile = [&](const f32x4 (&a)[4], bf16_t* gbase, int r0) {
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const bf16_t* __re
     };
 
     // ---- stage Q, K, V, dO (rows >= L zero-filled) and lse ----
-    stage_tiles<4, (LP * 8 * 4 + 2 * AB_THREADS - 1) / (2 * AB_THREADS), LP>(Qs, qb, ld, C, dob, L);
+    stage_tiles<4, (LP * 8 * 4 + 2 * AB_THREADS - 1) / (2 * AB_THREADS), LP>(Qs, qb, ld, part, dob, C, L);
     for (int q = threadIdx.x; q < LP; q += AB_THREADS) lse_s[q] = q < L ? lser[q] : 0.f;
     __syncthreads();
     const float scale = 0.125f;
@@ -541,6 +548,7 @@ extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, con
                              int heads, int causal, void* stream) {
     NEAT_REQUIRE(qkv && out, NEAT_ERR_ARG, "neat_attn_fwd: null pointer");
     NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_fwd: bad shape");
+    NEAT_REQUIRE(causal >= 0 && causal <= 3, NEAT_ERR_ARG, "neat_attn_fwd: flags %d (bit 0 causal, bit 1 head-major)", causal);
     NEAT_REQUIRE(!cu_seqlens || L <= 80, NEAT_ERR_SHAPE, "neat_attn_fwd: packed batches need L <= 80 (got %d)", L);
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
@@ -559,6 +567,7 @@ extern "C" int neat_attn_bwd(const uint16_t* qkv, const uint16_t* dout, const fl
                              const int32_t* cu_seqlens, int nseq, int L, int heads, int causal, void* stream) {
     NEAT_REQUIRE(qkv && dout && lse && dqkv, NEAT_ERR_ARG, "neat_attn_bwd: null pointer");
     NEAT_REQUIRE(nseq > 0 && L > 0 && heads > 0, NEAT_ERR_SHAPE, "neat_attn_bwd: bad shape");
+    NEAT_REQUIRE(causal >= 0 && causal <= 3, NEAT_ERR_ARG, "neat_attn_bwd: flags %d (bit 0 causal, bit 1 head-major)", causal);
     hipStream_t s = (hipStream_t)stream;
     switch (attn_nt(L)) {
         case 1: return launch_bwd<1>(qkv, dout, lse, dqkv, cu_seqlens, nseq, L, heads, causal, s);

@@ -30,13 +30,16 @@ class BlockWeights:
     def __init__(self, blk, need_bwd: bool):
         self.ln1_w, self.ln1_b = blk.ln_1.weight, blk.ln_1.bias
         self.ln2_w, self.ln2_b = blk.ln_2.weight, blk.ln_2.bias
-        mats = dict(qkv=blk.attn.in_proj_weight, o=blk.attn.out_proj.weight, fc=blk.mlp.c_fc.weight,
+        # the qkv projection is packed with its rows in head-major order ([head][q|k|v][64]): the attention kernels then
+        # read a head's three pieces as one 384-B run per token (ops.head_major_perm; frozen weights: permuted once)
+        perm = ops.head_major_perm(blk.attn.in_proj_weight.shape[1], blk.attn.in_proj_weight.device)
+        mats = dict(qkv=blk.attn.in_proj_weight.detach()[perm], o=blk.attn.out_proj.weight, fc=blk.mlp.c_fc.weight,
                     proj=blk.mlp.c_proj.weight)
         # packed once: weights are frozen during TTA (only LN gamma/beta adapt)
         self.w = {k: ops.pack_weight(v.detach().contiguous()) for k, v in mats.items()}
         self.wT = {k: ops.pack_weight(v.detach().contiguous(), transposed=True) for k, v in mats.items()} \
             if need_bwd else None
-        self.b = dict(qkv=blk.attn.in_proj_bias.detach(), o=blk.attn.out_proj.bias.detach(),
+        self.b = dict(qkv=blk.attn.in_proj_bias.detach()[perm].contiguous(), o=blk.attn.out_proj.bias.detach(),
                       fc=blk.mlp.c_fc.bias.detach(), proj=blk.mlp.c_proj.bias.detach())
 
 
@@ -55,7 +58,7 @@ class Stack:
         for w in self.blocks:
             y, _, mu1, rs1 = ops.ln_fwd(x, w.ln1_w, w.ln1_b, save_stats=save is not None)
             qkv, _ = ops.gemm(y, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
-            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None, cu=cu)
+            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None, cu=cu, head_major=True)
             x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
             y, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=save is not None)
             h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"],
@@ -84,7 +87,7 @@ class Stack:
                                   partial=parts[2 * j])
             dsts.append((g["ln2_w"], g["ln2_b"]))
             do, _ = ops.gemm(dxb, w.wT["o"], lib.EPI_BF16)
-            dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal, cu=cu)
+            dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal, cu=cu, head_major=True)
             dy1, _ = ops.gemm(dqkv, w.wT["qkv"], lib.EPI_BF16)
             dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, inplace_res=True,
                                   partial=parts[2 * j + 1])

@@ -296,28 +296,37 @@ def frames_preprocess(frames_u8, size=224, mean=CLIP_MEAN, std=CLIP_STD, out=Non
 
 
 # ---- attention ----
-def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None):
-    """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0]."""
+def attn_fwd(qkv, nseq, L, heads, causal, save_lse=True, cu=None, head_major=False):
+    """cu (int32 [nseq+1], packed batch) makes L the maximum sequence length; rows = qkv.shape[0].
+    head_major: qkv columns are [head][q|k|v][64] (``head_major_perm``) instead of [q|k|v][head][64]."""
     C = heads * 64
     rows = qkv.shape[0]
     if qkv.shape[1] != 3 * C or (cu is None and rows != nseq * L):
         raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} does not match nseq={nseq}, L={L}, C={C}")
     out = torch.empty(rows, C, dtype=bf16, device=qkv.device)
     lse = torch.empty(nseq, heads, L, dtype=f32, device=qkv.device) if save_lse else None
-    lib.call("neat_attn_fwd", _p(qkv, bf16, "qkv"), _p(out), _p(lse), _p(cu, i32, "cu"), nseq, L, heads, int(causal),
-             _stream())
+    lib.call("neat_attn_fwd", _p(qkv, bf16, "qkv"), _p(out), _p(lse), _p(cu, i32, "cu"), nseq, L, heads,
+             int(bool(causal)) | (2 if head_major else 0), _stream())
     return out, lse
 
 
-def attn_bwd(qkv, dout, lse, nseq, L, heads, causal, cu=None):
+def attn_bwd(qkv, dout, lse, nseq, L, heads, causal, cu=None, head_major=False):
     C = heads * 64
     rows = dout.shape[0]
     if qkv.shape[0] < rows or qkv.shape[1] != 3 * C or dout.shape[1] != C or (cu is None and rows != nseq * L):
         raise RuntimeError("attn_bwd: shape mismatch")
     dqkv = torch.empty(rows, 3 * C, dtype=bf16, device=qkv.device)
     lib.call("neat_attn_bwd", _p(qkv, bf16, "qkv"), _p(dout, bf16, "dout"), _p(lse, f32, "lse"), _p(dqkv),
-             _p(cu, i32, "cu"), nseq, L, heads, int(causal), _stream())
+             _p(cu, i32, "cu"), nseq, L, heads, int(bool(causal)) | (2 if head_major else 0), _stream())
     return dqkv
+
+
+def head_major_perm(C: int, device=None):
+    """Row permutation of an nn.MultiheadAttention in_proj weight / bias ([q | k | v] x [head] x 64 rows) that makes the
+    projection's output columns head-major: [head][q | k | v][64]."""
+    heads = C // 64
+    j = torch.arange(64, device=device)
+    return torch.cat([part * C + h * 64 + j for h in range(heads) for part in range(3)])
 
 
 # ---- embedding / pooled head ----

@@ -273,6 +273,25 @@ def test_attention_fwd_long_vision(L, heads):
     _attn_case(2, L, heads, False, 50 + L, bwd=False)
 
 
+@pytest.mark.parametrize("nseq,L,heads,causal", [(3, 77, 8, True), (2, 50, 12, False), (2, 197, 12, False)])
+def test_attention_head_major_layout_is_a_column_permutation(nseq, L, heads, causal):
+    """NEAT_ATTN_HEAD_MAJOR: qkv / dqkv columns ordered [head][q|k|v][64] (the in_proj rows permuted before packing) give
+    bit-identical outputs, and dqkv is the same permutation of the standard layout's dqkv."""
+    C = heads * 64
+    gen = g(70 + L)
+    qkv = (torch.randn(nseq * L, 3 * C, generator=gen) * 0.5).bfloat16().to(DEV)
+    perm = ops.head_major_perm(C, DEV)
+    qkv_hm = qkv[:, perm].contiguous()
+    o0, lse0 = ops.attn_fwd(qkv, nseq, L, heads, causal)
+    o1, lse1 = ops.attn_fwd(qkv_hm, nseq, L, heads, causal, head_major=True)
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    if L <= 80:
+        do = (torch.randn(nseq * L, C, generator=gen) * 0.1).bfloat16().to(DEV)
+        d0 = ops.attn_bwd(qkv, do, lse0, nseq, L, heads, causal)
+        d1 = ops.attn_bwd(qkv_hm, do, lse0, nseq, L, heads, causal, head_major=True)
+        assert torch.equal(d0[:, perm], d1)
+
+
 def test_attention_bwd_subset_of_sequences():
     """Backward over the first n sequences of a larger forward (the neg stream has no backward)."""
     nseq, L, heads = 6, 77, 8
