@@ -222,14 +222,33 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                         const int cl = lane % CPW, rq = lane / CPW;
                         const int n = nt0 * 16 + cl * 4;
                         const bool col_ok = cl * 4 < ncols;
+                        // The residual rows are loaded RES_AHEAD chunks ahead of their use (whole units only).  Loaded where
+                        // they are used, every load sat alone in the in-order vmcnt queue behind the previous chunk's
+                        // stores and the wave waited out one memory latency per 8 rows: 16 serial round trips per unit.
+                        constexpr int RES_AHEAD = 2;
+                        constexpr int NRD = 16 / RPI;
+                        constexpr bool PREFETCH = FULL && EPI == NEAT_EPI_BIAS_RES_F32;
+                        float4 rres[8][NRD];
+                        auto load_res = [&](int t) {
+#pragma unroll
+                            for (int r = 0; r < NRD; ++r)
+                                rres[t][r] = *reinterpret_cast<const float4*>(res + (long)(rowm0 + t * 16 + r * RPI + rq) * N + n);
+                        };
+                        if constexpr (PREFETCH) {
+#pragma unroll
+                            for (int t = 0; t < RES_AHEAD; ++t) load_res(t);
+                        }
 #pragma unroll
                         for (int t = 0; t < 8; ++t) {
                             char* sl = stg + (t & 1) * SLAB2;
 #pragma unroll
                             for (int i = 0; i < NI; ++i)
                                 *reinterpret_cast<f32x4*>(sl + fr * (CPW * 16) + (((i * 4 + fq) ^ (fr & (CPW - 1))) << 4)) = acc[i][t];
+                            if constexpr (PREFETCH) {
+                                if (t + RES_AHEAD < 8) load_res(t + RES_AHEAD);
+                            }
 #pragma unroll
-                            for (int r = 0; r < 16 / RPI; ++r) {
+                            for (int r = 0; r < NRD; ++r) {
                                 const int row = r * RPI + rq;
                                 const float4 a4 = *reinterpret_cast<const float4*>(sl + row * (CPW * 16) + ((cl ^ (row & (CPW - 1))) << 4));
                                 const int m = rowm0 + t * 16 + row;
@@ -238,7 +257,9 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                                 }
                                 const long o = (long)m * N + n;
                                 if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                                    const float4 rr = *reinterpret_cast<const float4*>(res + o);
+                                    float4 rr;
+                                    if constexpr (PREFETCH) rr = rres[t][r];
+                                    else rr = *reinterpret_cast<const float4*>(res + o);
                                     *reinterpret_cast<float4*>((float*)out0 + o) = make_float4(a4.x + rr.x, a4.y + rr.y, a4.z + rr.z, a4.w + rr.w);
                                 } else {
                                     *reinterpret_cast<float4*>((float*)out0 + o) = a4;
@@ -258,11 +279,26 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                         const char* rd1 = stg + er * 128 + (((2 * eq + 1) ^ sw(er)) << 4);
                         char* wr = stg + fr * 128;
                         const int wsw = sw(fr);
+                        // GELU': the saved pre-activation is requested H_AHEAD chunks ahead of its use, for the same reason as the
+                        // residual rows above
+                        constexpr bool PREFETCH_H = FULL && EPI == NEAT_EPI_GELU_BWD;
+                        uint4 hpre[8];
+                        constexpr int H_AHEAD = 4;
+                        auto load_h = [&](int t) {
+                            hpre[t] = *reinterpret_cast<const uint4*>(aux + (long)(rowm0 + t * 16 + er) * N + n);
+                        };
+                        if constexpr (PREFETCH_H) {
+#pragma unroll
+                            for (int t = 0; t < H_AHEAD; ++t) load_h(t);
+                        }
 #pragma unroll
                         for (int t = 0; t < 8; ++t) {
 #pragma unroll
                             for (int i = 0; i < NI; ++i)
                                 *reinterpret_cast<f32x4*>(wr + (t & 1) * SLAB2 + (((i * 4 + fq) ^ wsw) << 4)) = acc[i][t];
+                            if constexpr (PREFETCH_H) {
+                                if (t + H_AHEAD < 8) load_h(t + H_AHEAD);
+                            }
                             const float4 a0 = *reinterpret_cast<const float4*>(rd0 + (t & 1) * SLAB2);
                             const float4 a1 = *reinterpret_cast<const float4*>(rd1 + (t & 1) * SLAB2);
                             const int m = rowm0 + t * 16 + er;
@@ -287,7 +323,9 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                                 if (FULL || out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
                                 *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
                             } else {  // NEAT_EPI_GELU_BWD
-                                const uint4 hq = *reinterpret_cast<const uint4*>(aux + o);
+                                uint4 hq;
+                                if constexpr (PREFETCH_H) hq = hpre[t];
+                                else hq = *reinterpret_cast<const uint4*>(aux + o);
                                 const uint32_t hp[4] = {hq.x, hq.y, hq.z, hq.w};
                                 uint32_t dp[4];
 #pragma unroll
