@@ -424,6 +424,161 @@ __global__ __launch_bounds__(256) void topk_pairs_finish_kernel(const float* __r
     if (lane == 0) need[r] = (M < k && lost >= bv) || bi == IMAX;
 }
 
+// ---- transposed views by a tournament over chunks ------------------------------------------------------------------------
+// Logical row r of a transposed view is a strided column of the matrix in memory, so lanes must map to logical rows to keep
+// the loads coalesced, and a wave-instruction then serves 256 selections at once: per-lane insertion lists diverge at almost
+// every step (145 us + a 28-us merge for the 5 000 x 25 014 view = 2.8 TB/s).  Instead:
+//   pass 1 (topk_cols_chunk_kernel, one read of the matrix, branch-free, 5 VALU per element): the summed index is cut into
+//     chunks of CH elements; per (chunk, row) the maximum, where it is (first occurrence) and the SECOND largest value;
+//   pass 2 (topk_cols_select_kernel, reads 12 B per (chunk, row)): T = k-th largest of the row's chunk maxima (by lanes,
+//     ballot search as in the row kernel): at least k elements are >= T, so every winner is either a chunk maximum >= T or
+//     lives in a chunk whose second value is >= T too; only those chunks (1-3 per row) are read again, the candidates go
+//     through LDS and are placed by rank counting.  Exact; rows with too many candidates go to the exact tier.
+constexpr int COLS_MAXCHUNKS = 512;     // chunk planes of a select workgroup's rows in LDS: 512 x 5 x 12 B = 30 KiB
+constexpr int COLS_RESCAN_CAP = 32;
+constexpr int COLS_RB = 4;              // logical rows per select workgroup (one per wave)
+constexpr int COLS_P = COLS_RB + 1;     // LDS pitch of a chunk's row group
+
+static inline int cols_chunk_len(int Ncol) {
+    int ch = cdiv(Ncol, COLS_MAXCHUNKS);
+    ch = (ch + 7) / 8 * 8;
+    return ch < 64 ? 64 : ch;
+}
+
+__global__ __launch_bounds__(64) void topk_cols_chunk_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
+                                                             int CH, float* __restrict__ pmx, float* __restrict__ psc,
+                                                             int* __restrict__ pag) {
+    const int r0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (r0 >= R) return;
+    const int c0 = blockIdx.y * CH;
+    const int c1 = min(Ncol, c0 + CH);
+    float mx[4], sc[4];
+    int ag[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mx[q] = -INFINITY; sc[q] = -INFINITY; ag[q] = c0; }
+    auto take = [&](const f32x4& x, int c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = fmaxf(sc[q], fminf(x[q], mx[q]));
+            ag[q] = x[q] > mx[q] ? c : ag[q];
+            mx[q] = fmaxf(mx[q], x[q]);
+        }
+    };
+    const float* p = scores + r0;
+    int c = c0;
+    for (; c + 16 <= c1; c += 16) {                      // sixteen 16-B loads in flight per lane
+        f32x4 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (long)(c + j) * ld_col));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) take(x[j], c + j);
+    }
+    for (; c < c1; ++c) take(*reinterpret_cast<const f32x4*>(p + (long)c * ld_col), c);
+    const long o = (long)blockIdx.y * R + r0;
+    *reinterpret_cast<float4*>(pmx + o) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    *reinterpret_cast<float4*>(psc + o) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+    *reinterpret_cast<int4*>(pag + o) = make_int4(ag[0], ag[1], ag[2], ag[3]);
+}
+
+__global__ __launch_bounds__(256) void topk_cols_select_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
+                                                               int CH, int nchunk, const float* __restrict__ pmx,
+                                                               const float* __restrict__ psc, const int* __restrict__ pag,
+                                                               int k, int32_t* __restrict__ idx, float* __restrict__ val,
+                                                               int* __restrict__ need) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lmx = reinterpret_cast<float*>(smem);                   // [nchunk][COLS_RB + 1] (odd pitch: conflict-free down a column)
+    float* lsc = lmx + nchunk * COLS_P;
+    int* lag = reinterpret_cast<int*>(lsc + nchunk * COLS_P);
+    float* cv = reinterpret_cast<float*>(lag + nchunk * COLS_P);       // per wave: REG_CAP candidates + COLS_RESCAN_CAP chunk ids
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wcv = cv + wave * (2 * REG_CAP + COLS_RESCAN_CAP);
+    int* wci = reinterpret_cast<int*>(wcv + REG_CAP);
+    int* wrs = wci + REG_CAP;
+    const int r0 = blockIdx.x * COLS_RB;
+    for (int e = threadIdx.x; e < nchunk * COLS_RB; e += 256) {
+        const int c = e / COLS_RB, i = e % COLS_RB;
+        const bool in = r0 + i < R;
+        const long o = (long)c * R + r0 + i;
+        lmx[c * COLS_P + i] = in ? pmx[o] : -INFINITY;
+        lsc[c * COLS_P + i] = in ? psc[o] : -INFINITY;
+        lag[c * COLS_P + i] = in ? pag[o] : 0;
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    {                                                              // one logical row per wave: 24 waves per CU hide the
+        const int i = wave;                                        // latency of the (rare) second reads of a chunk
+        const int r = r0 + i;
+        if (r >= R) return;                                        // wave-uniform, after the only barrier
+        float m = -INFINITY;
+        for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, lmx[c * COLS_P + i]);
+        const uint32_t mk = order_key(m);
+        uint32_t t = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t cnd = t | (1u << b);
+            if (__popcll(__ballot(mk >= cnd)) >= k) t = cnd;
+        }
+        const float T = __uint_as_float((t & 0x80000000u) ? (t & 0x7fffffffu) : ~t);
+        int base = 0, nres = 0;                                    // wave-uniform counts
+        for (int cb = 0; cb < nchunk; cb += 64) {
+            const int c = cb + lane;
+            const bool in = c < nchunk;
+            const float v = in ? lmx[c * COLS_P + i] : -INFINITY;
+            const bool p = in && v >= T;
+            const unsigned long long b = __ballot(p);
+            if (b) {
+                const int pos = base + __popcll(b & lt_mask);
+                if (p && pos < REG_CAP) { wcv[pos] = v; wci[pos] = lag[c * COLS_P + i]; }
+                base += __popcll(b);
+            }
+            const bool p2 = in && lsc[c * COLS_P + i] >= T;
+            const unsigned long long b2 = __ballot(p2);
+            if (b2) {
+                const int pos = nres + __popcll(b2 & lt_mask);
+                if (p2 && pos < COLS_RESCAN_CAP) wrs[pos] = c;
+                nres += __popcll(b2);
+            }
+        }
+        bool ok = T > -INFINITY && nres <= COLS_RESCAN_CAP;
+        if (ok) {
+            for (int j = 0; j < nres; ++j) {                       // chunks with a second element at or above T: read again
+                const int c = wrs[j];
+                const int skip = lag[c * COLS_P + i];                  // the chunk maximum is already a candidate
+                const int c0 = c * CH, c1 = min(Ncol, c0 + CH);
+                for (int cc = c0 + lane; cc - lane < c1; cc += 64) {
+                    const bool in = cc < c1;
+                    const float v = in ? scores[(long)cc * ld_col + r] : -INFINITY;
+                    const bool p = in && v >= T && cc != skip;
+                    const unsigned long long b = __ballot(p);
+                    if (b) {
+                        const int pos = base + __popcll(b & lt_mask);
+                        if (p && pos < REG_CAP) { wcv[pos] = v; wci[pos] = cc; }
+                        base += __popcll(b);
+                    }
+                }
+            }
+            ok = base <= REG_CAP && base >= k;
+        }
+        if (ok) {
+            const bool have = lane < base;
+            const float v = have ? wcv[lane] : -INFINITY;
+            const int c = have ? wci[lane] : IMAX;
+            const uint32_t kv = order_key(v);
+            int place = 0;
+            for (int j = 0; j < base; ++j) {
+                const uint32_t ov = __builtin_amdgcn_readlane(kv, j);
+                const int oc = __builtin_amdgcn_readlane(c, j);
+                place += (ov > kv || (ov == kv && oc < c)) ? 1 : 0;
+            }
+            if (have && place < k) {
+                idx[(long)r * k + place] = c;
+                if (val) val[(long)r * k + place] = v;
+            }
+        }
+        if (lane == 0) need[r] = ok ? 0 : 1;
+    }
+}
+
 // recall[r] = (# of top-k indices that are positives) / (# positives in row r)
 __global__ __launch_bounds__(256) void recall_rows_kernel(const int32_t* __restrict__ idx, const uint8_t* __restrict__ pos,
                                                           long ld_row, int R, int Ncol, int k, float* __restrict__ recall) {
@@ -647,6 +802,7 @@ struct TopkWs {                // carve-up of the caller's workspace (all 256-B 
     int* need;                 // [R]
     float* fv; int* fi;        // fast tier: [R][nsf][SHORT_M]
     float* flost;              // [R][nsf]
+    float* pmx; float* psc; int* pag;   // transposed views: [nchunk][R] maximum, second value, position of the maximum
     long bytes;
 };
 static TopkWs topk_carve(void* ws, int R, int Ncol, int k) {
@@ -659,6 +815,10 @@ static TopkWs topk_carve(void* ws, int R, int Ncol, int k) {
     w.fv = reinterpret_cast<float*>(p + off); off += up(nsf * SHORT_M * (long)R * 4);
     w.fi = reinterpret_cast<int*>(p + off); off += up(nsf * SHORT_M * (long)R * 4);
     w.flost = reinterpret_cast<float*>(p + off); off += up(nsf * (long)R * 4);
+    const long nch = cdiv(Ncol, cols_chunk_len(Ncol));             // tournament planes of the transposed-view path
+    w.pmx = reinterpret_cast<float*>(p + off); off += up(nch * (long)R * 4);
+    w.psc = reinterpret_cast<float*>(p + off); off += up(nch * (long)R * 4);
+    w.pag = reinterpret_cast<int*>(p + off); off += up(nch * (long)R * 4);
     w.bytes = off;
     return w;
 }
@@ -714,6 +874,21 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
     } else {
         const int nsf = topk_fast_nsplit(R, Ncol);
         const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_col % 4 == 0) && (R % 4 == 0);
+        const int CH = cols_chunk_len(Ncol);
+        const int nchunk = cdiv(Ncol, CH);
+        if (vec && nchunk >= 64) {                                       // tournament over chunks (wide transposed views)
+            hipLaunchKernelGGL(topk_cols_chunk_kernel, dim3(cdiv(R, 256), nchunk), dim3(64), 0, s, scores, ld_col, R, Ncol, CH,
+                               w.pmx, w.psc, w.pag);
+            const size_t lds = (size_t)nchunk * COLS_P * 12 + 4 * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;
+            static unsigned long long attr_done = 0;
+            constexpr int lds_max = COLS_MAXCHUNKS * COLS_P * 12 + 4 * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;   // set once, for any nchunk
+            if (int rc = ensure_dynamic_lds((const void*)topk_cols_select_kernel, lds_max, &attr_done, "topk_cols_select attr")) return rc;
+            hipLaunchKernelGGL(topk_cols_select_kernel, dim3(cdiv(R, COLS_RB)), dim3(256), lds, s, scores, ld_col, R, Ncol, CH, nchunk,
+                               w.pmx, w.psc, w.pag, k, idx, val, w.need);
+            TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, false>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, ld_col, R, Ncol, k, idx, val, w.need));
+            NEAT_LAUNCH_CHECK("neat_topk_rows");
+            return NEAT_OK;
+        }
         if (vec) hipLaunchKernelGGL((topk_cols_fast_kernel<SHORT_M, 4>), dim3(cdiv(R, 256), nsf), dim3(64), 0, s, scores, ld_col, R, Ncol, nsf, w.fv, w.fi, w.flost);
         else hipLaunchKernelGGL((topk_cols_fast_kernel<SHORT_M, 1>), dim3(cdiv(R, 64), nsf), dim3(64), 0, s, scores, ld_col, R, Ncol, nsf, w.fv, w.fi, w.flost);
         hipLaunchKernelGGL((topk_pairs_finish_kernel<SHORT_M>), dim3(cdiv(R, 4)), dim3(256), 0, s, w.fv, w.fi, w.flost, R, nsf, k, idx, val, w.need);

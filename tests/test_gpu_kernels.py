@@ -644,6 +644,28 @@ def test_recall_from_embeddings_equals_materialised_scores():
     assert a == b and a["image_retrieval_recall@10"] > 0.05
 
 
+def test_topk_transposed_view_tournament():
+    """Wide transposed views go through the chunk tournament (per-chunk maximum / second value, then only the chunks
+    that can hold a winner are read again): planted duplicates inside one chunk and across chunks, a logical row full of
+    equal values (too many candidates -> exact tier), -inf entries, several k, against the oracle."""
+    for n_rows, n_cols, seed in ((5000, 64, 41), (8200, 36, 42), (40000, 16, 43)):
+        phys = torch.randn(n_rows, n_cols, generator=g(seed))        # logical matrix = phys.T: [n_cols, n_rows]
+        phys[100:110, 1] = 7.0                                       # ten equal winners inside one chunk
+        phys[::700, 2] = 6.5                                         # equal winners spread over many chunks
+        phys[:, 3] = -0.5                                            # every value equal
+        phys[::2, 4] = float("-inf")
+        phys[:, 5] = float("-inf")
+        phys[17, 5] = 0.0
+        phys[n_rows - 1, 6] = 9.0                                    # winner in the last (partial) chunk
+        d = phys.to(DEV)
+        for k in (1, 5, 10, 32):
+            val, idx = ops.topk_rows(d.T, k)
+            rv, ri = O.topk_rows(phys.T.contiguous(), k)
+            finite = torch.isfinite(rv)
+            assert torch.equal(val.cpu(), rv), (n_rows, n_cols, k)
+            assert torch.equal(idx.cpu().long()[finite], ri[finite]), (n_rows, n_cols, k)
+
+
 def test_topk_ties_lowest_index_first():
     z = load_golden("recall")
     tie = torch.from_numpy(z["tie_scores"])
