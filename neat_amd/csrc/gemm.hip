@@ -445,6 +445,8 @@ constexpr int T_BUF = 4 * T_HALF;             // one K-tile: A0 A1 B0 B1
 constexpr int T_BIAS = 2 * T_BUF;             // fp32 bias copy behind the two K-tile buffers
 constexpr int T_MAXN = 8192;
 constexpr int T_LDS = T_BIAS + T_MAXN * 4;    // 160 KiB
+constexpr int T_SLAB_MAXN = 4096;             // with N <= 4096 the bias copy needs 16 KiB: the other 16 KiB hold ...
+constexpr int T_SLAB = T_BIAS + T_SLAB_MAXN * 4;   // ... eight wave-private 2-KiB epilogue slabs
 constexpr int T_A0 = 0, T_B0 = 2;                // half-tile slots of a K-tile buffer: A0 A1 B0 B1
 
 __host__ __device__ __forceinline__ int t_swz(int lr) { return ((lr >> 1) & 7) ^ (((lr >> 4) & 1) << 1); }
@@ -640,6 +642,61 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
                     *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
                 }
             };
+            // Store shape.  Straight from the accumulators a wave-instruction covers 16 rows x 64 B, and a CU cannot push
+            // that shape out faster than ~30 GB/s however idle HBM is; whole 128-B lines (8 rows x 128 B) go at up to
+            // ~75 GB/s per CU (tools/store_probe.hip).  So each 16 x 64 row tile takes a round trip through a wave-private
+            // 2-KiB LDS slab (the upper half of the bias area, free while N <= 4096; 16-B chunks XOR-swizzled by the row,
+            // conflict-free both ways) and leaves as 8 rows x 128 B per instruction.
+            if constexpr (EPI != NEAT_EPI_GELU_BWD) {
+                if (N <= T_SLAB_MAXN) {
+                    char* slab = lds + T_SLAB + wave * 2048;
+                    char* wp0 = slab + fr * 128 + ((fq ^ (fr & 7)) << 4);            // h = 0 chunk; h = 1: chunk index + 4
+                    char* wp1 = slab + fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+                    const int rr = lane >> 3, cc = lane & 7;                         // row (0..7, +8) and 16-B chunk read back
+                    const char* rp0 = slab + rr * 128 + ((cc ^ (rr & 7)) << 4);
+                    const char* rp1 = slab + (rr + 8) * 128 + ((cc ^ ((rr + 8) & 7)) << 4);
+                    const int mbase = row0 + wr * 128 + rr;
+                    const long ocol = col0 + wc * 64 + cc * 8;
+                    auto through = [&](const uint4& a, const uint4& b, bf16_t* dst, int t, int rowlim) {
+                        *reinterpret_cast<uint4*>(wp0) = a;
+                        *reinterpret_cast<uint4*>(wp1) = b;
+                        const uint4 x0 = *reinterpret_cast<const uint4*>(rp0);
+                        const uint4 x1 = *reinterpret_cast<const uint4*>(rp1);
+                        const int m0 = mbase + 16 * t, m1 = m0 + 8;
+                        if (m0 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m0 * N + ocol) = x0;
+                        if (m1 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m1 * N + ocol) = x1;
+                    };
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        uint4 pk[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
+                            pk[h] = make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]));
+                        }
+                        if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                            // the saved pre-activation is the bf16-rounded value; GELU sees the same rounded value
+                            if (out0) through(pk[0], pk[1], (bf16_t*)out0, t, rows0 < M ? rows0 : M);
+                            uint4 up[2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t hp[4] = {pk[h].x, pk[h].y, pk[h].z, pk[h].w};
+                                uint32_t uq[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                    uq[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
+                                }
+                                up[h] = make_uint4(uq[0], uq[1], uq[2], uq[3]);
+                            }
+                            through(up[0], up[1], (bf16_t*)out1, t, M);
+                        } else {
+                            through(pk[0], pk[1], (bf16_t*)out0, t, M);
+                        }
+                    }
+                    return;
+                }
+            }
             if constexpr (EPI == NEAT_EPI_GELU_BWD) {
                 uint4 hq[8][2];                                    // the whole wave tile of h: 16 loads in flight
 #pragma unroll
