@@ -78,7 +78,7 @@ int neat_gemm_bf16(const uint16_t* A, const uint16_t* Wp, const float* bias, con
                    const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                    void* stream);
 /* The same GEMM in its second form ("tile256": 256 x 256 units, one workgroup per CU, both operands by LDS-DMA, see
- * csrc/gemm.hip), for N % 256 == 0, K % 128 == 0, N <= 8192.  Its weights are packed into the kernel's LDS image:
+ * csrc/gemm.hip), for N % 256 == 0, K % 128 == 0, N <= 4096 (wider layers take neat_gemm_bf16).  Its weights are packed into the kernel's LDS image:
  * 16-KiB half-tiles ((cb*(K/64) + kt)*2 + h), each 128 rows x 8 chunks of 16 B; row lr holds column
  * cb*256 + (lr>>5)*64 + h*32 + (lr&31), chunk p holds k = kt*64 + (p ^ swz(lr))*8 .. +7,
  * swz(lr) = ((lr>>1)&7) ^ (((lr>>4)&1)<<1).  Same arguments, epilogues and results as neat_gemm_bf16 (bf16 operands,

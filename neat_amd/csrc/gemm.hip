@@ -443,10 +443,9 @@ constexpr int T_THREADS = 512;
 constexpr int T_HALF = 16384;                 // bytes of a half-tile
 constexpr int T_BUF = 4 * T_HALF;             // one K-tile: A0 A1 B0 B1
 constexpr int T_BIAS = 2 * T_BUF;             // fp32 bias copy behind the two K-tile buffers
-constexpr int T_MAXN = 8192;
-constexpr int T_LDS = T_BIAS + T_MAXN * 4;    // 160 KiB
-constexpr int T_SLAB_MAXN = 4096;             // with N <= 4096 the bias copy needs 16 KiB: the other 16 KiB hold ...
-constexpr int T_SLAB = T_BIAS + T_SLAB_MAXN * 4;   // ... eight wave-private 2-KiB epilogue slabs
+constexpr int T_MAXN = 4096;                  // fp32 bias copy: 16 KiB
+constexpr int T_SLAB = T_BIAS + T_MAXN * 4;   // eight wave-private 2-KiB epilogue slabs
+constexpr int T_LDS = T_SLAB + 8 * 2048;      // 160 KiB
 constexpr int T_A0 = 0, T_B0 = 2;                // half-tile slots of a K-tile buffer: A0 A1 B0 B1
 
 __host__ __device__ __forceinline__ int t_swz(int lr) { return ((lr >> 1) & 7) ^ (((lr >> 4) & 1) << 1); }
@@ -606,147 +605,137 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // Epilogue.  Store (and load) SHAPE: straight from the accumulators a wave-instruction covers 16 rows x 64 B, and a CU
+    // cannot move that shape faster than ~30 GB/s however idle HBM is; whole 128-B lines (8 rows x 128 B) go at up to
+    // ~75 GB/s per CU (tools/store_probe.hip).  So every 16-row x 128-B piece of the wave's tile takes a round trip through
+    // a wave-private 2-KiB LDS slab (behind the bias copy; 16-B chunks XOR-swizzled by the row: conflict-free both ways):
+    // written in the accumulator layout (lane = row fr, 16-B chunk 4 j + fq), read back as lane = (row l >> 3 and + 8,
+    // chunk l & 7), so that every global access of the epilogue -- outputs, residual rows, saved pre-activation -- is
+    // 8 rows x 128 B per instruction.  W is the MFMA A operand, so a lane's accumulator quad is 4 consecutive columns; for
+    // bf16 outputs the interleaved column order of the weight fragments makes two quads 8 consecutive columns (16 B).
     auto epilogue = [&](int row0, int col0) {
-        const int mrow = row0 + wr * 128 + fr;                     // + 16 t
+        char* slab = lds + T_SLAB + wave * 2048;
+        char* ap0 = slab + fr * 128 + ((fq ^ (fr & 7)) << 4);                // accumulator-layout position, j = 0
+        char* ap1 = slab + fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);          //                              j = 1
+        const int rr = lane >> 3, cc = lane & 7;
+        char* lp0 = slab + rr * 128 + ((cc ^ (rr & 7)) << 4);                // line-layout position, rows rr and rr + 8
+        char* lp1 = slab + (rr + 8) * 128 + ((cc ^ ((rr + 8) & 7)) << 4);
+        const int mbase = row0 + wr * 128 + rr;                              // + 16 t (+ 8)
         if constexpr (PERM) {
-            const int ncol = col0 + wc * 64 + 8 * fq;              // + 32 h
-            auto emit = [&](int t, int h, const uint4* hq) {
-                const int m = mrow + 16 * t;
-                const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
-                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const long o = (long)m * N + ncol + 32 * h;
-                if (m >= M) return;
-                if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
-                    *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
-                        pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-                } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
-                    // the saved pre-activation is the bf16-rounded value; GELU sees the same rounded value
-                    uint32_t hp[4], up[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
-                        const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
-                        up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
-                    }
-                    // the pre-activation is kept for the first rows0 rows only (rows without a backward pass skip it)
-                    if (out0 && m < rows0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-                    *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
-                } else {  // NEAT_EPI_GELU_BWD
-                    const uint32_t hp[4] = {hq->x, hq->y, hq->z, hq->w};
-                    uint32_t dp[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
-                        dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
-                    }
-                    *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
-                }
+            const long ocol = col0 + wc * 64 + cc * 8;
+            auto leave = [&](const uint4& a, const uint4& b, bf16_t* dst, int t, int rowlim) {
+                *reinterpret_cast<uint4*>(ap0) = a;
+                *reinterpret_cast<uint4*>(ap1) = b;
+                const uint4 x0 = *reinterpret_cast<const uint4*>(lp0);
+                const uint4 x1 = *reinterpret_cast<const uint4*>(lp1);
+                const int m0 = mbase + 16 * t, m1 = m0 + 8;
+                if (m0 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m0 * N + ocol) = x0;
+                if (m1 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m1 * N + ocol) = x1;
             };
-            // Store shape.  Straight from the accumulators a wave-instruction covers 16 rows x 64 B, and a CU cannot push
-            // that shape out faster than ~30 GB/s however idle HBM is; whole 128-B lines (8 rows x 128 B) go at up to
-            // ~75 GB/s per CU (tools/store_probe.hip).  So each 16 x 64 row tile takes a round trip through a wave-private
-            // 2-KiB LDS slab (the upper half of the bias area, free while N <= 4096; 16-B chunks XOR-swizzled by the row,
-            // conflict-free both ways) and leaves as 8 rows x 128 B per instruction.
-            if constexpr (EPI != NEAT_EPI_GELU_BWD) {
-                if (N <= T_SLAB_MAXN) {
-                    char* slab = lds + T_SLAB + wave * 2048;
-                    char* wp0 = slab + fr * 128 + ((fq ^ (fr & 7)) << 4);            // h = 0 chunk; h = 1: chunk index + 4
-                    char* wp1 = slab + fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
-                    const int rr = lane >> 3, cc = lane & 7;                         // row (0..7, +8) and 16-B chunk read back
-                    const char* rp0 = slab + rr * 128 + ((cc ^ (rr & 7)) << 4);
-                    const char* rp1 = slab + (rr + 8) * 128 + ((cc ^ ((rr + 8) & 7)) << 4);
-                    const int mbase = row0 + wr * 128 + rr;
-                    const long ocol = col0 + wc * 64 + cc * 8;
-                    auto through = [&](const uint4& a, const uint4& b, bf16_t* dst, int t, int rowlim) {
-                        *reinterpret_cast<uint4*>(wp0) = a;
-                        *reinterpret_cast<uint4*>(wp1) = b;
-                        const uint4 x0 = *reinterpret_cast<const uint4*>(rp0);
-                        const uint4 x1 = *reinterpret_cast<const uint4*>(rp1);
-                        const int m0 = mbase + 16 * t, m1 = m0 + 8;
-                        if (m0 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m0 * N + ocol) = x0;
-                        if (m1 < rowlim) *reinterpret_cast<uint4*>(dst + (long)m1 * N + ocol) = x1;
-                    };
+            constexpr int HA = 4;                                  // GELU': row tiles of h requested ahead of their use
+            struct H2 { uint4 a, b; };
+            auto load_hq = [&](int t) -> H2 {
+                int m0 = mbase + 16 * t, m1 = m0 + 8;
+                m0 = m0 < M ? m0 : M - 1;
+                m1 = m1 < M ? m1 : M - 1;
+                return H2{*reinterpret_cast<const uint4*>(aux + (long)m0 * N + ocol),
+                          *reinterpret_cast<const uint4*>(aux + (long)m1 * N + ocol)};
+            };
+            H2 hq[8];
+            if constexpr (EPI == NEAT_EPI_GELU_BWD) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        uint4 pk[2];
+                for (int t = 0; t < HA; ++t) hq[t] = load_hq(t);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                uint4 pk[2];
+                if constexpr (EPI == NEAT_EPI_GELU_BWD) {
+                    // the saved pre-activation arrives as whole lines and is turned into the accumulator layout
+                    if (t + HA < 8) hq[t + HA] = load_hq(t + HA);
+                    *reinterpret_cast<uint4*>(lp0) = hq[t].a;
+                    *reinterpret_cast<uint4*>(lp1) = hq[t].b;
+                    const uint4 hh[2] = {*reinterpret_cast<const uint4*>(ap0), *reinterpret_cast<const uint4*>(ap1)};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
+                        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const uint32_t hp[4] = {hh[h].x, hh[h].y, hh[h].z, hh[h].w};
+                        uint32_t dp[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                            dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
+                        }
+                        pk[h] = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+                    }
+                    leave(pk[0], pk[1], (bf16_t*)out0, t, M);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
+                        pk[h] = make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]));
+                    }
+                    if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                        // the saved pre-activation is the bf16-rounded value (kept for the first rows0 rows only: rows without
+                        // a backward pass skip it); GELU sees the same rounded value
+                        if (out0) leave(pk[0], pk[1], (bf16_t*)out0, t, rows0 < M ? rows0 : M);
+                        uint4 up[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const f32x4 lo = acc[2 * h][t], hi = acc[2 * h + 1][t];
-                            pk[h] = make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]));
-                        }
-                        if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
-                            // the saved pre-activation is the bf16-rounded value; GELU sees the same rounded value
-                            if (out0) through(pk[0], pk[1], (bf16_t*)out0, t, rows0 < M ? rows0 : M);
-                            uint4 up[2];
+                            const uint32_t hp[4] = {pk[h].x, pk[h].y, pk[h].z, pk[h].w};
+                            uint32_t uq[4];
 #pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const uint32_t hp[4] = {pk[h].x, pk[h].y, pk[h].z, pk[h].w};
-                                uint32_t uq[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
-                                    uq[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
-                                }
-                                up[h] = make_uint4(uq[0], uq[1], uq[2], uq[3]);
+                            for (int q = 0; q < 4; ++q) {
+                                const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                uq[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
                             }
-                            through(up[0], up[1], (bf16_t*)out1, t, M);
-                        } else {
-                            through(pk[0], pk[1], (bf16_t*)out0, t, M);
+                            up[h] = make_uint4(uq[0], uq[1], uq[2], uq[3]);
                         }
+                        leave(up[0], up[1], (bf16_t*)out1, t, M);
+                    } else {
+                        leave(pk[0], pk[1], (bf16_t*)out0, t, M);
                     }
-                    return;
                 }
-            }
-            if constexpr (EPI == NEAT_EPI_GELU_BWD) {
-                uint4 hq[8][2];                                    // the whole wave tile of h: 16 loads in flight
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    int m = mrow + 16 * t;
-                    m = m < M ? m : M - 1;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        hq[t][h] = *reinterpret_cast<const uint4*>(aux + (long)m * N + ncol + 32 * h);
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) emit(t, h, &hq[t][h]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) emit(t, h, nullptr);
             }
         } else {
-            const int ncol = col0 + wc * 64 + 4 * fq;              // + 16 i
-            // residual rows are loaded two row tiles (8 loads) ahead of their use; res may alias out0 (in place):
-            // a lane only ever re-reads what it has not yet written
-            float4 rr[3][4];
-            auto load_res = [&](int t) {
-                int m = mrow + 16 * t;
-                m = m < M ? m : M - 1;
+            // fp32 outputs: two 32-column halves per row tile (16 rows x 128 B each).  The residual rows are loaded as whole
+            // lines too, two row tiles ahead of their use; res may alias out0 (in place): a lane reads exactly the positions
+            // it later writes, and reads them first.
+            const long ocol = col0 + wc * 64 + cc * 4;                       // + 32 p
+            float4 rq[3][4];                                                 // [t % 3][2 p + row half]
+            auto load_rq = [&](int t) {
+                int m0 = mbase + 16 * t, m1 = m0 + 8;
+                m0 = m0 < M ? m0 : M - 1;
+                m1 = m1 < M ? m1 : M - 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rr[t % 3][i] = *reinterpret_cast<const float4*>(res + (long)m * N + ncol + 16 * i);
+                for (int pq = 0; pq < 2; ++pq) {
+                    rq[t % 3][2 * pq] = *reinterpret_cast<const float4*>(res + (long)m0 * N + ocol + 32 * pq);
+                    rq[t % 3][2 * pq + 1] = *reinterpret_cast<const float4*>(res + (long)m1 * N + ocol + 32 * pq);
+                }
             };
             if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                load_res(0);
-                load_res(1);
+                load_rq(0);
+                load_rq(1);
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                    if (t + 2 < 8) load_res(t + 2);
+                    if (t + 2 < 8) load_rq(t + 2);
                 }
-                const int m = mrow + 16 * t;
+                const int m0 = mbase + 16 * t, m1 = m0 + 8;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 a4 = acc[i][t];
-                    float4 o4 = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                for (int pq = 0; pq < 2; ++pq) {
+                    *reinterpret_cast<f32x4*>(ap0) = acc[2 * pq][t];
+                    *reinterpret_cast<f32x4*>(ap1) = acc[2 * pq + 1][t];
+                    float4 x0 = *reinterpret_cast<const float4*>(lp0);
+                    float4 x1 = *reinterpret_cast<const float4*>(lp1);
                     if constexpr (EPI == NEAT_EPI_BIAS_RES_F32) {
-                        const float4 r4 = rr[t % 3][i];
-                        o4.x += r4.x, o4.y += r4.y, o4.z += r4.z, o4.w += r4.w;
+                        const float4 r0 = rq[t % 3][2 * pq], r1 = rq[t % 3][2 * pq + 1];
+                        x0.x += r0.x, x0.y += r0.y, x0.z += r0.z, x0.w += r0.w;
+                        x1.x += r1.x, x1.y += r1.y, x1.z += r1.z, x1.w += r1.w;
                     }
-                    if (m < M) *reinterpret_cast<float4*>((float*)out0 + (long)m * N + ncol + 16 * i) = o4;
+                    if (m0 < M) *reinterpret_cast<float4*>((float*)out0 + (long)m0 * N + ocol + 32 * pq) = x0;
+                    if (m1 < M) *reinterpret_cast<float4*>((float*)out0 + (long)m1 * N + ocol + 32 * pq) = x1;
                 }
             }
         }

@@ -153,7 +153,7 @@ class PackedWeight:
 
 
 def t256_shape_ok(N, K):
-    return N % 256 == 0 and K % 128 == 0 and N <= 8192
+    return N % 256 == 0 and K % 128 == 0 and N <= 4096
 
 
 # NEAT_GEMM=panel | t256 forces one kernel wherever its shape rules allow (A/B timing); default: the library's choice
