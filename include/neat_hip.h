@@ -260,7 +260,7 @@ int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int
 /* Fused similarity + top-k for the offline path: replaces `texts_emb @ images_emb.t()` (evaluation/retrieval.py:70) and
  * the torch.topk of recall_at_k (:294-300) in one call that never holds the [Nq, Ng] score matrix in HBM.  Q f32 [Nq,D],
  * G f32 [Ng,D] (row-major, D % 16 == 0) -> idx i32 [Nq,k] (rows of G, best first, ties -> lowest index), val f32 [Nq,k]
- * (may be NULL).  The scores go through ws (neat_sim_topk_ws_bytes bytes, 256-B aligned) in row chunks of at most 64 MiB,
+ * (may be NULL).  The scores go through ws (neat_sim_topk_ws_bytes bytes, 256-B aligned) in row chunks of at most 128 MiB,
  * which stay in the Infinity Cache between the exact-fp32 GEMM that writes them and the selection that reads them.
  * Results are bit-identical to neat_gemm_f32_nt followed by neat_topk_rows.  For the other direction swap Q and G. */
 long neat_sim_topk_ws_bytes(int Nq, int Ng, int k);

@@ -73,7 +73,7 @@ int check_hip(hipError_t e, const char* what);
     } while (0)
 
 // loss.hip: C[M,N] = A[M,K] . B[N,K]^T, exact fp32 FMA chains in k order; K % 16 == 0
-int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s);
+int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, long ldc, hipStream_t s);   // ldc: row pitch of C (floats)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per device (bit d of `done`),
 // not per process.  Call before launching `fn` with more than 64 KiB of dynamic LDS.

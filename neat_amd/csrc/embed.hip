@@ -329,7 +329,7 @@ extern "C" int neat_pool_proj_fwd(const float* x, const int32_t* row_idx, const 
     float* z = ws;
     hipLaunchKernelGGL(pool_ln_fwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, x, row_idx, gamma, beta, z, xe, mean, rstd,
                        nseq, L, C, eps);
-    int rc = launch_gemm_f32_nt(z, proj_t, feat, nseq, D, C, s);
+    int rc = launch_gemm_f32_nt(z, proj_t, feat, nseq, D, C, D, s);
     if (rc) return rc;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(PP_THREADS), 0, s, feat, nrm, nseq, D, normalize);
     NEAT_LAUNCH_CHECK("neat_pool_proj_fwd");
@@ -354,7 +354,7 @@ extern "C" int neat_pool_proj_bwd(const float* dfeat, const float* feat, const f
         hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, dfeat, feat, nrm, df, nseq, D);
         dfp = df;
     }
-    int rc = launch_gemm_f32_nt(dfp, proj, dz, nseq, C, D, s);     // dz[n,C] = df[n,D] . proj[C,D]^T
+    int rc = launch_gemm_f32_nt(dfp, proj, dz, nseq, C, D, C, s);     // dz[n,C] = df[n,D] . proj[C,D]^T
     if (rc) return rc;
     hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3(grid), dim3(PP_THREADS), 0, s, dz, xe, mean, rstd, gamma, row_idx, dx_f32,
                        dx_bf16, nseq, L, C);

@@ -69,6 +69,7 @@ struct SgProb {
     float* C;
     int M, N, K;
     long lda, ldb;
+    long ldc;     // row pitch of C in floats; 0 = N
 };
 
 template <bool A_KM, bool B_KM>
@@ -104,13 +105,132 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(SgProb p0, SgProb p1
         __syncthreads();
     }
     const int n = n0 + wn + (lane & 31);
+    const long ldc = p.ldc ? p.ldc : p.N;
     if (n < p.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm + sg_row(r, lane);
-            if (m < p.M) p.C[(long)m * p.N + n] = acc[r];
+            if (m < p.M) p.C[(long)m * ldc + n] = acc[r];
         }
     }
+}
+
+// The same product for LARGE problems (the 25 014 x 5 000 x 512 retrieval similarity): 128 x 128 outputs per workgroup, 4 waves
+// as 2 x 2, each with a 64 x 64 register tile = four 32 x 32 accumulators, so a k-pair costs 4 LDS reads for 4 MFMAs instead
+// of 2 for 1.  Every output is still the k-ascending fmaf chain of the kernel above: bit-identical results.  Two workgroups
+// per CU (34 KiB of LDS, < 128 VGPRs) take turns on the matrix pipe.  Workgroups are dealt to the XCDs (blockIdx % 8) in
+// 8 x 8 super-tiles, so the 64 workgroups an XCD runs at once share 2 MiB of A rows and 2 MiB of B rows in its 4-MiB L2.
+constexpr int SB_T = 128;
+constexpr int SB_LD = SB_T + 4;
+constexpr int SB_SLAB = SG_K * SB_LD;
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int ntm, int ntn) {
+    __shared__ __attribute__((aligned(16))) float As[2][SB_SLAB], Bs[2][SB_SLAB];
+    const int SN = (ntn + 7) >> 3, SM = (ntm + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = (j >> 6) * 8 + xcd;                            // super-tile number
+    if (g >= SM * SN) return;                                    // uniform per workgroup, before any barrier
+    const int tm = (g / SN) * 8 + ((j & 63) >> 3), tn = (g % SN) * 8 + (j & 7);
+    if (tm >= ntm || tn >= ntn) return;
+    const int m0 = tm * SB_T, n0 = tn * SB_T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // operand slab [128 rows x 16 k]: thread -> rows t>>2 and 64 + (t>>2), k quad t&3 (two 16-B loads per operand)
+    const int lr = threadIdx.x >> 2, kq = threadIdx.x & 3;
+    const float* ap[2];
+    const float* bp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int ra = m0 + h * 64 + lr, rb = n0 + h * 64 + lr;
+        ra = ra < p.M ? ra : p.M - 1;
+        rb = rb < p.N ? rb : p.N - 1;
+        ap[h] = p.A + (long)ra * p.lda + kq * 4;
+        bp[h] = p.B + (long)rb * p.ldb + kq * 4;
+    }
+    auto put = [&](float* dst, const float4& v, int h) {            // k-major slabs, as in the kernel above
+        float* d = dst + (kq * 4) * SB_LD + h * 64 + lr;
+        d[0] = v.x;
+        d[SB_LD] = v.y;
+        d[2 * SB_LD] = v.z;
+        d[3 * SB_LD] = v.w;
+    };
+    // slab s is computed from LDS while slab s+1 waits in registers (loaded one whole slab ago: an L2 miss has 2 x 2 048
+    // MFMA cycles to arrive) and slab s+2 is being requested
+    float4 va[2], vb[2], na[2], nb[2];
+    const int ns = p.K / SG_K;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        va[h] = *reinterpret_cast<const float4*>(ap[h]);
+        vb[h] = *reinterpret_cast<const float4*>(bp[h]);
+    }
+    if (ns > 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            na[h] = *reinterpret_cast<const float4*>(ap[h] + SG_K);
+            nb[h] = *reinterpret_cast<const float4*>(bp[h] + SG_K);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        put(As[0], va[h], h);
+        put(Bs[0], vb[h], h);
+    }
+    __syncthreads();
+    const int fo = (lane >> 5) * SB_LD + (lane & 31);
+    for (int s = 0; s < ns; ++s) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            va[h] = na[h];
+            vb[h] = nb[h];
+        }
+        if (s + 2 < ns) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                na[h] = *reinterpret_cast<const float4*>(ap[h] + (s + 2) * SG_K);
+                nb[h] = *reinterpret_cast<const float4*>(bp[h] + (s + 2) * SG_K);
+            }
+        }
+        const float* as = As[s & 1] + fo + wm;
+        const float* bs = Bs[s & 1] + fo + wn;
+#pragma unroll
+        for (int kk = 0; kk < SG_K / 2; ++kk) {
+            const float a0 = as[2 * kk * SB_LD], a1 = as[2 * kk * SB_LD + 32];
+            const float b0 = bs[2 * kk * SB_LD], b1 = bs[2 * kk * SB_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < ns) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                put(As[(s + 1) & 1], va[h], h);
+                put(Bs[(s + 1) & 1], vb[h], h);
+            }
+        }
+        __syncthreads();
+    }
+    const long ldc = p.ldc ? p.ldc : p.N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn + b * 32 + (lane & 31);
+            if (n < p.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + a * 32 + sg_row(r, lane);
+                    if (m < p.M) p.C[(long)m * ldc + n] = acc[a][b][r];
+                }
+            }
+        }
 }
 
 // Fused coarse alignment tile: S = q G^T (stored), A = (pos G^T)(1 - relu(neg G^T)) -> per-row
@@ -383,10 +503,18 @@ static void launch_sg(const SgProb& p0, const SgProb* p1, hipStream_t s) {
                        p0, p1 ? *p1 : p0);
 }
 
-int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t s) {
+int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, long ldc, hipStream_t s) {
     NEAT_REQUIRE(A && B && C, NEAT_ERR_ARG, "gemm_f32_nt: null pointer");
     NEAT_REQUIRE(M > 0 && N > 0 && K > 0 && K % SG_K == 0, NEAT_ERR_SHAPE, "gemm_f32_nt: K=%d must be a multiple of 16", K);
-    launch_sg<false, false>(SgProb{A, B, C, M, N, K, K, K}, nullptr, s);
+    NEAT_REQUIRE(ldc >= N, NEAT_ERR_SHAPE, "gemm_f32_nt: ldc=%ld < N=%d", ldc, N);
+    const int ntm = cdiv(M, SB_T), ntn = cdiv(N, SB_T);
+    if ((long)ntm * ntn >= 512) {                                // a full chip of 128 x 128 tiles: the large-problem kernel
+        const int nsup = cdiv(ntm, 8) * cdiv(ntn, 8);
+        hipLaunchKernelGGL(gemm_f32_mfma128_kernel, dim3(cdiv(nsup, 8) * 8 * 64), dim3(256), 0, s,
+                           SgProb{A, B, C, M, N, K, K, K, ldc}, ntm, ntn);
+    } else {
+        launch_sg<false, false>(SgProb{A, B, C, M, N, K, K, K, ldc}, nullptr, s);
+    }
     NEAT_LAUNCH_CHECK("gemm_f32_nt");
     return NEAT_OK;
 }
@@ -396,7 +524,7 @@ int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, i
 using namespace neat;
 
 extern "C" int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
-    return launch_gemm_f32_nt(A, B, C, M, N, K, (hipStream_t)stream);
+    return launch_gemm_f32_nt(A, B, C, M, N, K, N, (hipStream_t)stream);
 }
 
 extern "C" long neat_coarse_ws_floats(int B, int N) { return 2L * B * cdiv(N, SG_T); }

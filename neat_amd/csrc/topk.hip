@@ -167,17 +167,24 @@ __device__ __forceinline__ uint32_t order_key(float x) {                  // a <
 
 template <int NV>
 __global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restrict__ scores, long ld_row, int R, int Ncol,
-                                                            int k, int32_t* __restrict__ idx, float* __restrict__ val,
-                                                            int* __restrict__ need) {
+                                                            int S, int seg_len, int k, int32_t* __restrict__ idx,
+                                                            float* __restrict__ val, int* __restrict__ need) {
+    // S > 1: rows wider than a wave's registers are cut into S segments of seg_len columns (a multiple of 4); a wave then
+    // selects the top k of ONE segment (virtual row r * S + segment; idx / val / need are indexed by virtual row and
+    // topk_seg_merge_kernel picks the row's k winners among its S * k candidates).  S == 1: seg_len = Ncol, as before.
     __shared__ float cv[4][REG_CAP];
     __shared__ int ci[4][REG_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nvec = Ncol >> 2, rem = Ncol & 3;
     float* wcv = cv[wave];
     int* wci = ci[wave];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
-        const float* row = scores + (long)r * ld_row;
+    const int nvirt = R * S;
+    for (int vr = blockIdx.x * 4 + wave; vr < nvirt; vr += gridDim.x * 4) {
+        const int r = S == 1 ? vr : vr / S;
+        const int c_off = (vr - r * S) * seg_len;
+        const int ncol = min(seg_len, Ncol - c_off);
+        const int nvec = ncol >> 2, rem = ncol & 3;
+        const float* row = scores + (long)r * ld_row + c_off;
         const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
         f32x4 x[NV];
 #pragma unroll
@@ -212,11 +219,11 @@ __global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restr
         for (int j = 0; j < NV; ++j) {
             const float m4 = fmaxf(fmaxf(x[j][0], x[j][1]), fmaxf(x[j][2], x[j][3]));
             if (__ballot(m4 >= T)) {
-                const int c0 = (lane + 64 * j) << 2;
+                const int c0 = c_off + ((lane + 64 * j) << 2);
                 push(x[j][0], c0); push(x[j][1], c0 + 1); push(x[j][2], c0 + 2); push(x[j][3], c0 + 3);
             }
         }
-        if (rem) push(xt, (nvec << 2) + lane);
+        if (rem) push(xt, c_off + (nvec << 2) + lane);
         const bool ok = base <= REG_CAP && base >= k && T > -INFINITY;    // wave-uniform
         if (ok) {
             // one candidate per lane; place = number of candidates that come before it
@@ -231,12 +238,44 @@ __global__ __launch_bounds__(256) void topk_rows_reg_kernel(const float* __restr
                 place += (ov > kv || (ov == kv && oc < c)) ? 1 : 0;
             }
             if (have && place < k) {
-                idx[(long)r * k + place] = c;
-                if (val) val[(long)r * k + place] = v;
+                idx[(long)vr * k + place] = c;
+                if (val) val[(long)vr * k + place] = v;
             }
         }
-        if (lane == 0) need[r] = ok ? 0 : 1;
+        if (lane == 0) need[vr] = ok ? 0 : 1;
     }
+}
+
+// The k winners of a row among the S * k (<= 64) candidates its segments produced, one wave per row, by the same rank
+// counting (value descending, lowest column first).  A row with a flagged segment is flagged as a whole for the exact tier.
+__global__ __launch_bounds__(256) void topk_seg_merge_kernel(const int32_t* __restrict__ sgi, const float* __restrict__ sgv,
+                                                             const int* __restrict__ sneed, int R, int S, int k,
+                                                             int32_t* __restrict__ idx, float* __restrict__ val,
+                                                             int* __restrict__ need) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const bool bad = lane < S && sneed[(long)r * S + lane] != 0;
+    if (__ballot(bad)) {
+        if (lane == 0) need[r] = 1;
+        return;
+    }
+    const int n = S * k;
+    const bool have = lane < n;
+    const float v = have ? sgv[(long)r * n + lane] : -INFINITY;
+    const int c = have ? sgi[(long)r * n + lane] : IMAX;
+    const uint32_t kv = order_key(v);
+    int place = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t ov = __builtin_amdgcn_readlane(kv, i);
+        const int oc = __builtin_amdgcn_readlane(c, i);
+        place += (ov > kv || (ov == kv && oc < c)) ? 1 : 0;
+    }
+    if (have && place < k) {
+        idx[(long)r * k + place] = c;
+        if (val) val[(long)r * k + place] = v;
+    }
+    if (lane == 0) need[r] = 0;
 }
 
 // The exact kernels (a k-entry list per lane).  need == NULL: every row; else only rows with need[r] != 0.
@@ -803,8 +842,16 @@ struct TopkWs {                // carve-up of the caller's workspace (all 256-B 
     float* fv; int* fi;        // fast tier: [R][nsf][SHORT_M]
     float* flost;              // [R][nsf]
     float* pmx; float* psc; int* pag;   // transposed views: [nchunk][R] maximum, second value, position of the maximum
+    int* sgi; float* sgv; int* sneed;   // segmented wide rows: [R][S][k] candidates, [R][S] flags
     long bytes;
 };
+// Rows wider than the register kernel holds (5 120 columns) are cut into S segments: seg_len a multiple of 4, at most 5 120.
+constexpr int REG_MAXCOLS = 20 * 256;
+static inline int topk_segments(int Ncol, int* seg_len) {
+    const int S = cdiv(Ncol, REG_MAXCOLS);
+    *seg_len = S <= 1 ? Ncol : (cdiv(Ncol, S) + 3) / 4 * 4;
+    return S;
+}
 static TopkWs topk_carve(void* ws, int R, int Ncol, int k) {
     auto up = [](long b) { return (b + 255) / 256 * 256; };
     const long nsf = topk_fast_nsplit(R, Ncol);
@@ -819,6 +866,12 @@ static TopkWs topk_carve(void* ws, int R, int Ncol, int k) {
     w.pmx = reinterpret_cast<float*>(p + off); off += up(nch * (long)R * 4);
     w.psc = reinterpret_cast<float*>(p + off); off += up(nch * (long)R * 4);
     w.pag = reinterpret_cast<int*>(p + off); off += up(nch * (long)R * 4);
+    int seg_len;
+    const long S = topk_segments(Ncol, &seg_len);
+    const long ncand = S > 1 && S * k <= 64 ? S * k : 0;
+    w.sgi = reinterpret_cast<int*>(p + off); off += up(ncand * R * 4);
+    w.sgv = reinterpret_cast<float*>(p + off); off += up(ncand * R * 4);
+    w.sneed = reinterpret_cast<int*>(p + off); off += up((ncand ? S : 0) * R * 4);
     w.bytes = off;
     return w;
 }
@@ -853,15 +906,26 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
     if (ld_col == 1) {
         const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_row % 4 == 0);
         const int nv = cdiv(Ncol >> 2, 64);                               // 16-B loads per lane that hold a whole row
-        const bool reg = vec && nv <= 20;                           // NV = 24 would need all 256 VGPRs
+        int seg_len;
+        const int S = topk_segments(Ncol, &seg_len);
+        // wider rows: S segments per row through the same kernel, then a merge of the S * k candidates (every segment must
+        // hold k columns, and a wave ranks at most 64 candidates)
+        const bool seg = vec && S > 1 && S * k <= 64 && Ncol - (S - 1) * seg_len >= k;
+        const bool reg = (vec && nv <= 20) || seg;                  // NV = 24 would need all 256 VGPRs
         if (reg) {
-#define TOPK_REG(NVV) hipLaunchKernelGGL((topk_rows_reg_kernel<NVV>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need)
-            if (nv <= 4) TOPK_REG(4);
-            else if (nv <= 8) TOPK_REG(8);
-            else if (nv <= 12) TOPK_REG(12);
-            else if (nv <= 16) TOPK_REG(16);
+            const int snv = seg ? cdiv(seg_len >> 2, 64) : nv;
+            int rgrid = cdiv(seg ? R * S : R, 4);
+            rgrid = rgrid > 16384 ? 16384 : rgrid;
+#define TOPK_REG(NVV)                                                                                                      \
+    hipLaunchKernelGGL((topk_rows_reg_kernel<NVV>), dim3(rgrid), dim3(256), 0, s, scores, ld_row, R, Ncol, seg ? S : 1,     \
+                       seg ? seg_len : Ncol, k, seg ? w.sgi : idx, seg ? w.sgv : val, seg ? w.sneed : w.need)
+            if (snv <= 4) TOPK_REG(4);
+            else if (snv <= 8) TOPK_REG(8);
+            else if (snv <= 12) TOPK_REG(12);
+            else if (snv <= 16) TOPK_REG(16);
             else TOPK_REG(20);
 #undef TOPK_REG
+            if (seg) hipLaunchKernelGGL(topk_seg_merge_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, w.sgi, w.sgv, w.sneed, R, S, k, idx, val, w.need);
         } else if (vec) hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, true>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
         else hipLaunchKernelGGL((topk_rows_fast_kernel<SHORT_M, false>), dim3(grid), dim3(256), 0, s, scores, ld_row, R, Ncol, k, idx, val, w.need);
         if (k > SHORT_M || reg) {
@@ -961,13 +1025,14 @@ extern "C" int neat_mcq_scores(const float* img, const float* txt, float* logits
 // ---- fused similarity + top-k: the offline path's `texts_emb @ images_emb.t()` (evaluation/retrieval.py:70) followed by
 // torch.topk (:294-300), without the [Nq, Ng] score matrix in HBM.  The scores are produced SIM_CHUNK-bounded row chunks at
 // a time by the exact-fp32 MFMA GEMM into the caller's workspace and reduced by the row kernels above before the next
-// chunk overwrites them: a chunk (<= 64 MiB) stays in the 256 MiB Infinity Cache between its producer and its consumer,
+// chunk overwrites them: a chunk (<= 128 MiB: two rounds of 128 x 128 GEMM tiles; 64 MiB, one round, measured 12 % slower
+// end to end) stays in the 256 MiB Infinity Cache between its producer and its consumer,
 // so HBM sees Q and G once per chunk and the k winners, not 2 x Nq x Ng x 4 bytes.  Bit-identical to
 // neat_gemm_f32_nt + neat_topk_rows (same kernels, same order of operations).
-extern "C" int neat_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+static inline long sim_pitch(int Ng) { return ((long)Ng + 3) / 4 * 4; }   // chunk rows start 16-B aligned for the row kernels
 
 static inline int sim_chunk_rows(int Nq, int Ng) {
-    long rows = (64L << 20) / (4L * Ng);
+    long rows = (128L << 20) / (4L * sim_pitch(Ng));
     rows = rows / 128 * 128;
     if (rows < 128) rows = 128;
     return (int)(rows < Nq ? rows : Nq);
@@ -976,7 +1041,7 @@ static inline int sim_chunk_rows(int Nq, int Ng) {
 extern "C" long neat_sim_topk_ws_bytes(int Nq, int Ng, int k) {
     if (Nq <= 0 || Ng <= 0 || k < 1) return 256;
     const int ch = sim_chunk_rows(Nq, Ng);
-    const long sc = ((long)ch * Ng * 4 + 255) / 256 * 256;
+    const long sc = ((long)ch * sim_pitch(Ng) * 4 + 255) / 256 * 256;
     return sc + neat_topk_ws_bytes(ch, Ng, k);
 }
 
@@ -988,11 +1053,12 @@ extern "C" int neat_sim_topk(const float* Q, const float* G, int k, int32_t* idx
                  "neat_sim_topk: Nq=%d Ng=%d D=%d k=%d (need D %% 16 == 0, 1 <= k <= min(32, Ng))", Nq, Ng, D, k);
     const int ch = sim_chunk_rows(Nq, Ng);
     float* sc = reinterpret_cast<float*>(ws);
-    void* tws = reinterpret_cast<char*>(ws) + ((long)ch * Ng * 4 + 255) / 256 * 256;
+    const long pitch = sim_pitch(Ng);
+    void* tws = reinterpret_cast<char*>(ws) + ((long)ch * pitch * 4 + 255) / 256 * 256;
     for (int q0 = 0; q0 < Nq; q0 += ch) {
         const int rows = Nq - q0 < ch ? Nq - q0 : ch;
-        if (int rc = neat_gemm_f32_nt(Q + (long)q0 * D, G, sc, rows, Ng, D, stream)) return rc;
-        if (int rc = neat_topk_rows(sc, Ng, 1, rows, Ng, k, idx_out + (long)q0 * k, val_out ? val_out + (long)q0 * k : nullptr,
+        if (int rc = launch_gemm_f32_nt(Q + (long)q0 * D, G, sc, rows, Ng, D, pitch, (hipStream_t)stream)) return rc;
+        if (int rc = neat_topk_rows(sc, pitch, 1, rows, Ng, k, idx_out + (long)q0 * k, val_out ? val_out + (long)q0 * k : nullptr,
                                     tws, stream))
             return rc;
     }

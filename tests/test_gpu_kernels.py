@@ -607,6 +607,34 @@ def test_topk_register_resident_rows():
             assert torch.equal(idx.cpu().long()[finite], ri[finite]), (n, k)
 
 
+def test_topk_wide_contiguous_rows_in_segments():
+    """Contiguous rows wider than 5 120 columns are cut into S segments for the register kernel and the S * k candidates
+    merged per row: ties planted inside a segment, across two segments and on a segment boundary, a constant row (exact
+    tier), -inf entries, a row with fewer finite values than k, widths with S = 2, 3 and 5 (25 014 = the caption count)
+    incl. a view with a row pitch, and k too large for the merge (S * k > 64 -> the earlier path), against the oracle."""
+    for n, seed in ((5124, 51), (10241, 52), (12003, 53), (25014, 54)):
+        pitch = (n + 3) // 4 * 4
+        full = torch.randn(7, pitch, generator=g(seed))
+        m = full[:, :n]
+        S = -(-n // 5120)
+        seg = (-(-n // S) + 3) // 4 * 4
+        m[0, 10:20] = m[0, seg + 3: seg + 13] = 7.0                  # equal winners in two segments: lowest columns first
+        m[1, seg - 2: seg + 2] = 8.0                                 # ties straddling a segment boundary
+        m[2] = -1.5                                                  # constant row
+        m[3, ::2] = float("-inf")
+        m[4] = float("-inf")
+        m[4, n - 1] = 2.0
+        m[5, :] = torch.round(m[5] * 4) / 4
+        d = full.to(DEV)[:, :n]                                      # a strided view: 16-B aligned rows, pitch != columns
+        assert d.stride(0) == pitch
+        for k in (1, 5, 10, 12, 32):
+            val, idx = ops.topk_rows(d, k)
+            rv, ri = O.topk_rows(m.contiguous(), k)
+            finite = torch.isfinite(rv)
+            assert torch.equal(val.cpu(), rv), (n, k)
+            assert torch.equal(idx.cpu().long()[finite], ri[finite]), (n, k)
+
+
 def test_sim_topk_equals_gemm_then_topk():
     """neat_sim_topk (scores only ever in a cache-sized workspace chunk) against the materialised path, bit for bit:
     several chunks with a ragged last one (4 000 queries x 5 000 gallery rows: chunks of 3 328), both directions, planted
@@ -622,6 +650,15 @@ def test_sim_topk_equals_gemm_then_topk():
             v0, i0 = ops.topk_rows(S, k)
             v1, i1 = ops.sim_topk(a, b, k)
             assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    # a gallery wider than the register kernel and not a multiple of 4 (the i2t direction: 25 014 captions): the workspace
+    # chunk gets a 16-B aligned row pitch and the rows go through the segmented path
+    Gw = torch.nn.functional.normalize(torch.randn(10242, 64, generator=gen), dim=-1)
+    Gw[9000:9030] = Gw[40:70]
+    gw = Gw.to(DEV)
+    v0, i0 = ops.topk_rows(ops.gemm_f32_nt(q[:900].contiguous(), gw), 10)
+    v1, i1 = ops.sim_topk(q[:900].contiguous(), gw, 10)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    assert torch.equal(i1.cpu().long(), O.topk_rows(ops.gemm_f32_nt(q[:900].contiguous(), gw).cpu(), 10)[1])
     Qs, Gs = Q[:37].contiguous(), G[3990:4060].contiguous()
     v, i = ops.sim_topk(Qs.to(DEV), Gs.to(DEV), 5)
     S_ref = O.similarity(Qs, Gs) if hasattr(O, "similarity") else None
@@ -741,6 +778,21 @@ def test_gemm_f32_nt():
     A = torch.randn(300, 512, generator=g(1)); B = torch.randn(77, 512, generator=g(2))
     Cm = ops.gemm_f32_nt(A.to(DEV), B.to(DEV))
     assert rel_l2(Cm.cpu(), A @ B.t()) < 1e-6
+
+
+def test_gemm_f32_nt_large_kernel_is_bit_identical_to_the_tile_kernel():
+    """From 512 tiles of 128 x 128 on, neat_gemm_f32_nt runs the 128 x 128 kernel (four accumulators per wave, XCD super
+    tiles).  Every output must still be the same k-ascending fmaf chain: the product computed in row blocks small enough for
+    the 64 x 64 kernel is equal bit for bit, ragged edges in both dimensions included; and an integer-valued case is exact."""
+    A = torch.randn(2900, 80, generator=g(41)).to(DEV)
+    B = torch.randn(4003, 80, generator=g(42)).to(DEV)
+    big = ops.gemm_f32_nt(A, B)                                   # 23 x 32 = 736 tiles
+    small = torch.cat([ops.gemm_f32_nt(A[i:i + 128].contiguous(), B) for i in range(0, A.shape[0], 128)])
+    assert torch.equal(big, small)
+    assert rel_l2(big.cpu().double(), A.cpu().double() @ B.cpu().double().t()) < 1e-6
+    Ai = torch.randint(-8, 9, (2900, 64), generator=g(43)).float().to(DEV)
+    Bi = torch.randint(-8, 9, (4003, 64), generator=g(44)).float().to(DEV)
+    assert torch.equal(ops.gemm_f32_nt(Ai, Bi).cpu(), (Ai.cpu().double() @ Bi.cpu().double().t()).float())
 
 
 def test_errors_are_loud():

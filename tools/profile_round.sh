@@ -17,5 +17,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tk 
 cp $(ls $O/tk/*/*kernel_stats.csv | head -1) $O/topk_kernel_stats.csv
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_tk -- python3 tools/topk_bench.py > $O/pmc_tk.log 2>&1 || exit 1
 python3 tools/summarize_pmc.py $(ls $O/pmc_tk/*/*counter_collection.csv | head -1) $O/topk_pmc_fetch_size.csv || exit 1
+# exact-fp32 similarity GEMM: rate per shape, and how busy the matrix pipe is (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))
+timeout -k 10 120 python3 tools/f32_gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/sim_gemm_f32.txt
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sg -- python3 tools/f32_gemm_bench.py 25014x5000x512 > $O/pmc_sg.log 2>&1 || exit 1
+python3 tools/summarize_pmc.py $(ls $O/pmc_sg/*/*counter_collection.csv $O/pmc_sg/*counter_collection.csv 2>/dev/null | head -1) $O/sim_gemm_pmc_mfma_busy.csv || exit 1
+rm -rf $O/pmc_sg
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/tk $O/pmc_tk
 head -8 $O/bench_kernel_stats.csv | cut -c1-160; head -6 $O/bench_pmc_fetch_size.csv | cut -c1-200; head -6 $O/bench_pmc_write_size.csv | cut -c1-200

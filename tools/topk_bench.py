@@ -38,6 +38,11 @@ us, (_, it) = timed(lambda: ops.topk_rows(scores, 10))
 print(f"top-10 rows  (t2i, {NT} rows x {NI}):      {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s of 8 = {byts / us / 8e6:.3f}")
 us, (_, ii) = timed(lambda: ops.topk_rows(scores.T, 10))
 print(f"top-10 cols  (i2t, {NI} rows x {NT}, view): {us:9.1f} us  {byts / us / 1e6:6.2f} TB/s of 8 = {byts / us / 8e6:.3f}")
+wide = torch.empty(1280, (NT + 3) // 4 * 4, device=dev)[:, :NT]      # one fused-i2t chunk: 1 280 images x 25 014 captions
+wide.copy_(scores.T[:1280])
+us, _ = timed(lambda: ops.topk_rows(wide, 10))
+wb = 1280 * NT * 4
+print(f"top-10 rows  (1280 contiguous rows x {NT}, 5 segments + merge): {us:9.1f} us  {wb / us / 1e6:6.2f} TB/s (chunk is cache-resident)")
 us, _ = timed(lambda: ops.sim_topk(txt, img, 10), 3)
 print(f"fused similarity + top-10 (t2i, scores never in HBM as a whole):        {us:9.1f} us")
 us, _ = timed(lambda: ops.sim_topk(img, txt, 10), 3)
