@@ -115,16 +115,22 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(SgProb p0, SgProb p1
     }
 }
 
-// The same product for LARGE problems (the 25 014 x 5 000 x 512 retrieval similarity): 128 x 128 outputs per workgroup, 4 waves
-// as 2 x 2, each with a 64 x 64 register tile = four 32 x 32 accumulators, so a k-pair costs 4 LDS reads for 4 MFMAs instead
-// of 2 for 1.  Every output is still the k-ascending fmaf chain of the kernel above: bit-identical results.  Two workgroups
-// per CU (34 KiB of LDS, < 128 VGPRs) take turns on the matrix pipe.  Workgroups are dealt to the XCDs (blockIdx % 8) in
-// 8 x 8 super-tiles, so the 64 workgroups an XCD runs at once share 2 MiB of A rows and 2 MiB of B rows in its 4-MiB L2.
+// The same product for LARGE problems (the 25 014 x 5 000 x 512 retrieval similarity): 128 x 128 outputs per workgroup, 8 waves
+// as 2 x 4, each with a 64 x 32 register tile = two 32 x 32 accumulators (3 LDS reads per 2 MFMAs instead of 2 per 1), and a
+// global -> register -> LDS pipeline two slabs deep.  Every output is still the k-ascending fmaf chain of the kernel above:
+// bit-identical results.  Four workgroups per CU (34 KiB of LDS, 71 VGPRs) take turns on the matrix pipe.  Workgroups are
+// dealt to the XCDs (blockIdx % 8) in 8 x 8 super-tiles, so the 64 workgroups an XCD runs at once share 2 MiB of A rows and
+// 2 MiB of B rows in its 4-MiB L2.  Measured (25 014 x 5 000): SQ_VALU_MFMA_BUSY_CYCLES = 80 % of the SIMD cycles at the
+// 2.07 GHz the chip holds under it; between K = 512 and K = 1 024 the marginal rate is 150 TFLOP/s, the rest is per-tile
+// (first loads 5 %, C stores 2.5 %, the partial last round 4 %); the 4-wave form (64 x 64 per wave) measured the same.
 constexpr int SB_T = 128;
 constexpr int SB_LD = SB_T + 4;
 constexpr int SB_SLAB = SG_K * SB_LD;
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int ntm, int ntn) {
+template <int NW>   // waves per workgroup: 4 (wave tile 64 x 64) or 8 (64 x 32)
+__global__ __launch_bounds__(NW * 64) void gemm_f32_mfma128_kernel(SgProb p, int ntm, int ntn) {
+    constexpr int BT = 8 / NW;          // 32-column accumulator tiles per wave
+    constexpr int H = 8 / NW;           // 16-B loads per thread, operand and slab
     __shared__ __attribute__((aligned(16))) float As[2][SB_SLAB], Bs[2][SB_SLAB];
     const int SN = (ntn + 7) >> 3, SM = (ntm + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -134,28 +140,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int 
     if (tm >= ntm || tn >= ntn) return;
     const int m0 = tm * SB_T, n0 = tn * SB_T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave / (NW / 2)) * 64, wn = (wave % (NW / 2)) * (32 * BT);
+    f32x16 acc[2][BT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < BT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     // operand slab [128 rows x 16 k]: thread -> rows t>>2 and 64 + (t>>2), k quad t&3 (two 16-B loads per operand)
     const int lr = threadIdx.x >> 2, kq = threadIdx.x & 3;
-    const float* ap[2];
-    const float* bp[2];
+    constexpr int RP = NW * 16;         // rows per load pass
+    const float* ap[H];
+    const float* bp[H];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int ra = m0 + h * 64 + lr, rb = n0 + h * 64 + lr;
+    for (int h = 0; h < H; ++h) {
+        int ra = m0 + h * RP + lr, rb = n0 + h * RP + lr;
         ra = ra < p.M ? ra : p.M - 1;
         rb = rb < p.N ? rb : p.N - 1;
         ap[h] = p.A + (long)ra * p.lda + kq * 4;
         bp[h] = p.B + (long)rb * p.ldb + kq * 4;
     }
     auto put = [&](float* dst, const float4& v, int h) {            // k-major slabs, as in the kernel above
-        float* d = dst + (kq * 4) * SB_LD + h * 64 + lr;
+        float* d = dst + (kq * 4) * SB_LD + h * RP + lr;
         d[0] = v.x;
         d[SB_LD] = v.y;
         d[2 * SB_LD] = v.z;
@@ -163,22 +170,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int 
     };
     // slab s is computed from LDS while slab s+1 waits in registers (loaded one whole slab ago: an L2 miss has 2 x 2 048
     // MFMA cycles to arrive) and slab s+2 is being requested
-    float4 va[2], vb[2], na[2], nb[2];
+    float4 va[H], vb[H], na[H], nb[H];
     const int ns = p.K / SG_K;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < H; ++h) {
         va[h] = *reinterpret_cast<const float4*>(ap[h]);
         vb[h] = *reinterpret_cast<const float4*>(bp[h]);
     }
     if (ns > 1) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < H; ++h) {
             na[h] = *reinterpret_cast<const float4*>(ap[h] + SG_K);
             nb[h] = *reinterpret_cast<const float4*>(bp[h] + SG_K);
         }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < H; ++h) {
         put(As[0], va[h], h);
         put(Bs[0], vb[h], h);
     }
@@ -186,13 +193,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int 
     const int fo = (lane >> 5) * SB_LD + (lane & 31);
     for (int s = 0; s < ns; ++s) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < H; ++h) {
             va[h] = na[h];
             vb[h] = nb[h];
         }
         if (s + 2 < ns) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < H; ++h) {
                 na[h] = *reinterpret_cast<const float4*>(ap[h] + (s + 2) * SG_K);
                 nb[h] = *reinterpret_cast<const float4*>(bp[h] + (s + 2) * SG_K);
             }
@@ -202,15 +209,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int 
 #pragma unroll
         for (int kk = 0; kk < SG_K / 2; ++kk) {
             const float a0 = as[2 * kk * SB_LD], a1 = as[2 * kk * SB_LD + 32];
-            const float b0 = bs[2 * kk * SB_LD], b1 = bs[2 * kk * SB_LD + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                const float bv = bs[2 * kk * SB_LD + 32 * b];
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+            }
         }
         if (s + 1 < ns) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < H; ++h) {
                 put(As[(s + 1) & 1], va[h], h);
                 put(Bs[(s + 1) & 1], vb[h], h);
             }
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma128_kernel(SgProb p, int 
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < BT; ++b) {
             const int n = n0 + wn + b * 32 + (lane & 31);
             if (n < p.N) {
 #pragma unroll
@@ -510,7 +518,7 @@ int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, i
     const int ntm = cdiv(M, SB_T), ntn = cdiv(N, SB_T);
     if ((long)ntm * ntn >= 512) {                                // a full chip of 128 x 128 tiles: the large-problem kernel
         const int nsup = cdiv(ntm, 8) * cdiv(ntn, 8);
-        hipLaunchKernelGGL(gemm_f32_mfma128_kernel, dim3(cdiv(nsup, 8) * 8 * 64), dim3(256), 0, s,
+        hipLaunchKernelGGL(gemm_f32_mfma128_kernel<8>, dim3(cdiv(nsup, 8) * 8 * 64), dim3(512), 0, s,
                            SgProb{A, B, C, M, N, K, K, K, ldc}, ntm, ntn);
     } else {
         launch_sg<false, false>(SgProb{A, B, C, M, N, K, K, K, ldc}, nullptr, s);
