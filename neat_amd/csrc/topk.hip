@@ -468,20 +468,21 @@ __global__ __launch_bounds__(256) void topk_pairs_finish_kernel(const float* __r
 // the loads coalesced, and a wave-instruction then serves 256 selections at once: per-lane insertion lists diverge at almost
 // every step (145 us + a 28-us merge for the 5 000 x 25 014 view = 2.8 TB/s).  Instead:
 //   pass 1 (topk_cols_chunk_kernel, one read of the matrix, branch-free, 5 VALU per element): the summed index is cut into
-//     chunks of CH elements; per (chunk, row) the maximum, where it is (first occurrence) and the SECOND largest value;
+//     chunks of CH elements (>= 128: measured 64 / 128 / 256 -> 123 / 112 / 115 us on the 5 000 x 25 014 view); per (chunk,
+//     row) the maximum, where it is (first occurrence) and the SECOND largest value;
 //   pass 2 (topk_cols_select_kernel, reads 12 B per (chunk, row)): T = k-th largest of the row's chunk maxima (by lanes,
 //     ballot search as in the row kernel): at least k elements are >= T, so every winner is either a chunk maximum >= T or
-//     lives in a chunk whose second value is >= T too; only those chunks (1-3 per row) are read again, the candidates go
+//     lives in a chunk whose second value is >= T too; only those chunks (a few per row) are read again, the candidates go
 //     through LDS and are placed by rank counting.  Exact; rows with too many candidates go to the exact tier.
-constexpr int COLS_MAXCHUNKS = 512;     // chunk planes of a select workgroup's rows in LDS: 512 x 5 x 12 B = 30 KiB
+constexpr int COLS_MAXCHUNKS = 512;     // chunk planes of a select workgroup's rows in LDS: 512 x 9 x 12 B = 54 KiB
 constexpr int COLS_RESCAN_CAP = 32;
-constexpr int COLS_RB = 4;              // logical rows per select workgroup (one per wave)
+constexpr int COLS_RB = 8;              // logical rows per select workgroup (one per wave): 32 contiguous bytes per chunk plane
 constexpr int COLS_P = COLS_RB + 1;     // LDS pitch of a chunk's row group
 
 static inline int cols_chunk_len(int Ncol) {
     int ch = cdiv(Ncol, COLS_MAXCHUNKS);
     ch = (ch + 7) / 8 * 8;
-    return ch < 64 ? 64 : ch;
+    return ch < 128 ? 128 : ch;
 }
 
 __global__ __launch_bounds__(64) void topk_cols_chunk_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64) void topk_cols_chunk_kernel(const float* __rest
     *reinterpret_cast<int4*>(pag + o) = make_int4(ag[0], ag[1], ag[2], ag[3]);
 }
 
-__global__ __launch_bounds__(256) void topk_cols_select_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
+__global__ __launch_bounds__(COLS_RB * 64) void topk_cols_select_kernel(const float* __restrict__ scores, long ld_col, int R, int Ncol,
                                                                int CH, int nchunk, const float* __restrict__ pmx,
                                                                const float* __restrict__ psc, const int* __restrict__ pag,
                                                                int k, int32_t* __restrict__ idx, float* __restrict__ val,
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void topk_cols_select_kernel(const float* __re
     int* wci = reinterpret_cast<int*>(wcv + REG_CAP);
     int* wrs = wci + REG_CAP;
     const int r0 = blockIdx.x * COLS_RB;
-    for (int e = threadIdx.x; e < nchunk * COLS_RB; e += 256) {
+    for (int e = threadIdx.x; e < nchunk * COLS_RB; e += COLS_RB * 64) {
         const int c = e / COLS_RB, i = e % COLS_RB;
         const bool in = r0 + i < R;
         const long o = (long)c * R + r0 + i;
@@ -943,11 +944,11 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
         if (vec && nchunk >= 64) {                                       // tournament over chunks (wide transposed views)
             hipLaunchKernelGGL(topk_cols_chunk_kernel, dim3(cdiv(R, 256), nchunk), dim3(64), 0, s, scores, ld_col, R, Ncol, CH,
                                w.pmx, w.psc, w.pag);
-            const size_t lds = (size_t)nchunk * COLS_P * 12 + 4 * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;
+            const size_t lds = (size_t)nchunk * COLS_P * 12 + COLS_RB * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;
             static unsigned long long attr_done = 0;
-            constexpr int lds_max = COLS_MAXCHUNKS * COLS_P * 12 + 4 * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;   // set once, for any nchunk
+            constexpr int lds_max = COLS_MAXCHUNKS * COLS_P * 12 + COLS_RB * (2 * REG_CAP + COLS_RESCAN_CAP) * 4;   // set once, for any nchunk
             if (int rc = ensure_dynamic_lds((const void*)topk_cols_select_kernel, lds_max, &attr_done, "topk_cols_select attr")) return rc;
-            hipLaunchKernelGGL(topk_cols_select_kernel, dim3(cdiv(R, COLS_RB)), dim3(256), lds, s, scores, ld_col, R, Ncol, CH, nchunk,
+            hipLaunchKernelGGL(topk_cols_select_kernel, dim3(cdiv(R, COLS_RB)), dim3(COLS_RB * 64), lds, s, scores, ld_col, R, Ncol, CH, nchunk,
                                w.pmx, w.psc, w.pag, k, idx, val, w.need);
             TOPK_DISPATCH(kp, hipLaunchKernelGGL((topk_rows_kernel<KP, false>), dim3(xgrid), dim3(256), 0, s, scores, ld_row, ld_col, R, Ncol, k, idx, val, w.need));
             NEAT_LAUNCH_CHECK("neat_topk_rows");
