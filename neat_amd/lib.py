@@ -59,7 +59,7 @@ SIGNATURES = {
     "neat_recall_from_topk": (_I, [_P, _P, _L, _L, _I, _I, _I, _P, _P]),
     "neat_recall_owner_topk": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "neat_best_positive_rank": (_I, [_P, _L, _L, _P, _L, _L, _I, _I, _P, _P]),
-    "neat_best_positive_rank_owner": (_I, [_P, _L, _L, _P, _P, _I, _I, _P, _P]),
+    "neat_best_positive_rank_owner": (_I, [_P, _L, _L, _P, _P, _I, _I, _P, _P, _P]),
     "neat_mcq_scores": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "neat_gemm_f32_nt": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "neat_sim_topk_ws_bytes": (_L, [_I, _I, _I]),

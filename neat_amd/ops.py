@@ -563,8 +563,9 @@ def best_positive_rank_owner(scores, row_owner=None, col_owner=None):
     R, N = scores.shape
     sr, sc = scores.stride()
     out = torch.empty(R, dtype=i32, device=scores.device)
+    ws = torch.empty(8 * R, dtype=torch.uint8, device=scores.device)      # transposed views: best positive per logical row
     lib.call("neat_best_positive_rank_owner", scores.data_ptr(), sr, sc, _p(row_owner, i32, "row_owner"),
-             _p(col_owner, i32, "col_owner"), R, N, _p(out), _stream())
+             _p(col_owner, i32, "col_owner"), R, N, _p(out), _p(ws), _stream())
     return out
 
 

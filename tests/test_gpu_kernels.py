@@ -566,6 +566,31 @@ def test_recall_from_owner_vectors_equals_dense_and_golden():
         assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))      # 0/0 -> NaN on both paths
 
 
+def test_best_positive_rank_on_transposed_views_is_coalesced_and_equal():
+    """With a workspace, the owner form reads a transposed view once with lanes along the logical rows (64-bit atomic max
+    for the best positive, integer-atomic counts).  It must give the dense-bool kernel's ranks and the per-row kernel's
+    (ws = NULL): heavy ties (lowest column first), +0.0 / -0.0 (equal), logical rows without a positive, both owner kinds."""
+    from neat_amd import lib
+    n_txt, n_img = 3000, 1000
+    S = torch.round(torch.randn(n_txt, n_img, generator=g(61)) * 4) / 4          # a few hundred ties per value
+    S[::7, ::5] = -0.0
+    S[::11, ::3] = 0.0
+    owner = torch.randint(0, 900, (n_txt,), generator=g(62)).to(torch.int32)     # images 900.. own no caption
+    pos = torch.zeros(n_txt, n_img, dtype=torch.bool)
+    pos[torch.arange(n_txt), owner.long()] = True
+    Sd, od, pd = S.to(DEV), owner.to(DEV), pos.to(DEV)
+    fast = ops.best_positive_rank_owner(Sd.T, col_owner=od)                      # image -> text on the transposed view
+    assert torch.equal(fast, ops.best_positive_rank(Sd.T, pd.T))
+    assert (fast[900:] == 0).all() and (fast[:900] > 0).sum() > 800
+    slow = torch.empty(n_img, dtype=torch.int32, device=DEV)
+    lib.call("neat_best_positive_rank_owner", Sd.data_ptr(), 1, n_img, None, od.data_ptr(), n_img, n_txt, slow.data_ptr(),
+             None, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(fast, slow)
+    St = Sd.T.contiguous()                                                        # [n_img, n_txt]; its .T is text -> image
+    assert torch.equal(ops.best_positive_rank_owner(St.T, row_owner=od), ops.best_positive_rank(Sd, pd))
+    assert torch.equal(ops.best_positive_rank_owner(Sd, row_owner=od), ops.best_positive_rank(Sd, pd))
+
+
 def test_topk_vector_loads_and_unaligned_rows():
     """The row kernel reads 16 B per lane when rows are 16-B aligned: column counts that are not a multiple of 4, views
     with a row pitch, unaligned bases and pitches (4-B fallback) must all give the oracle's indices."""
