@@ -667,6 +667,31 @@ __global__ __launch_bounds__(64) void recall_cols_kernel(const int32_t* __restri
     recall[r] = tp / n;
 }
 
+// The same in two launches for tall views (the 5 000 x 25 014 one: 79 workgroups walking 25 014 flags each took 6 ms): the
+// positives of a logical row are counted by (row block, column chunk) workgroups into the recall buffer itself, as
+// integers (atomic adds: exact and order-independent), and the finish kernel turns the count into tp / n.
+__global__ __launch_bounds__(64) void recall_cols_count_kernel(const uint8_t* __restrict__ pos, long ld_col, int R, int Ncol,
+                                                               int CH, int* __restrict__ count) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const int c0 = blockIdx.y * CH, c1 = min(Ncol, c0 + CH);
+    int n = 0;
+    for (int c = c0; c < c1; ++c) n += pos[(long)c * ld_col + r] ? 1 : 0;
+    if (n) atomicAdd(count + r, n);
+}
+__global__ __launch_bounds__(64) void recall_cols_finish_kernel(const int32_t* __restrict__ idx, const uint8_t* __restrict__ pos,
+                                                                long ld_col, int R, int Ncol, int k, float* __restrict__ recall) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const float n = (float)reinterpret_cast<const int*>(recall)[r];
+    float tp = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int c = idx[(long)r * k + j];
+        if (c >= 0 && c < Ncol) tp += pos[(long)c * ld_col + r] ? 1.f : 0.f;
+    }
+    recall[r] = tp / n;
+}
+
 
 // Recall from ONE top-K list per row for several cut-offs at once, with the positives given as owner vectors instead
 // of a dense [R, Ncol] bool matrix (NegBench: caption t belongs to image txt2img[t]; reference evaluation/retrieval.py:
@@ -1048,7 +1073,15 @@ extern "C" int neat_recall_from_topk(const int32_t* idx, const uint8_t* pos, lon
         grid = grid > 8192 ? 8192 : grid;
         hipLaunchKernelGGL(recall_rows_kernel, dim3(grid), dim3(256), 0, s, idx, pos, ld_row, R, Ncol, k, recall);
     } else {
-        hipLaunchKernelGGL(recall_cols_kernel, dim3(cdiv(R, 64)), dim3(64), 0, s, idx, pos, ld_col, R, Ncol, k, recall);
+        if (Ncol >= 2048) {
+            constexpr int CH = 256;
+            if (int rc = check_hip(hipMemsetAsync(recall, 0, (size_t)R * 4, s), "neat_recall_from_topk memset")) return rc;
+            hipLaunchKernelGGL(recall_cols_count_kernel, dim3(cdiv(R, 64), cdiv(Ncol, CH)), dim3(64), 0, s, pos, ld_col, R, Ncol, CH,
+                               reinterpret_cast<int*>(recall));
+            hipLaunchKernelGGL(recall_cols_finish_kernel, dim3(cdiv(R, 64)), dim3(64), 0, s, idx, pos, ld_col, R, Ncol, k, recall);
+        } else {
+            hipLaunchKernelGGL(recall_cols_kernel, dim3(cdiv(R, 64)), dim3(64), 0, s, idx, pos, ld_col, R, Ncol, k, recall);
+        }
     }
     NEAT_LAUNCH_CHECK("neat_recall_from_topk");
     return NEAT_OK;

@@ -566,6 +566,22 @@ def test_recall_from_owner_vectors_equals_dense_and_golden():
         assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))      # 0/0 -> NaN on both paths
 
 
+def test_recall_dense_positives_on_tall_transposed_view():
+    """recall_at_k's dense positive_pairs form in the image -> text direction (a transposed bool view) counts the positives
+    of tall views in (row block, column chunk) workgroups; it must equal the owner-vector form, row by row (0/0 -> NaN)."""
+    n_txt, n_img = 2500, 600
+    S = torch.randn(n_txt, n_img, generator=g(71)).to(DEV)
+    owner = torch.randint(0, 550, (n_txt,), generator=g(72)).to(torch.int32)     # images 550.. own nothing -> NaN
+    pos = torch.zeros(n_txt, n_img, dtype=torch.bool)
+    pos[torch.arange(n_txt), owner.long()] = True
+    _, it = ops.topk_rows(S.T, 10)
+    a = ops.recall_from_topk(it, pos.to(DEV).T)
+    b = ops.recall_owner_topk(it, (10,), col_owner=owner.to(DEV), npos=torch.bincount(owner.long(), minlength=n_img).to(torch.int32).to(DEV))[0]
+    assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+    owns = torch.bincount(owner.long(), minlength=n_img) > 0
+    assert torch.equal(torch.isnan(a).cpu(), ~owns) and not owns[550:].any() and owns.sum() > 500
+
+
 def test_best_positive_rank_on_transposed_views_is_coalesced_and_equal():
     """With a workspace, the owner form reads a transposed view once with lanes along the logical rows (64-bit atomic max
     for the best positive, integer-atomic counts).  It must give the dense-bool kernel's ranks and the per-row kernel's
