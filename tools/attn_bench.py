@@ -7,6 +7,9 @@ from neat_amd import ops
 
 dev = "cuda"
 L, heads, C = 77, 8, 512
+SCALE = 1
+if len(sys.argv) > 1 and sys.argv[1] == "contig":     # upper bound of a [sequence][head][token][q|k|v] layout: one head per "sequence"
+    heads, C, SCALE = 1, 64, 8
 g = torch.Generator(device=dev).manual_seed(0)
 def med(fn, n=20):
     ts = []
@@ -17,7 +20,7 @@ def med(fn, n=20):
             ts.append(a.elapsed_time(b) * 1e3)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
-for nf, nb in ((1024, 768),):
+for nf, nb in ((1024 * SCALE, 768 * SCALE),):
     qkv = (torch.randn(nf * L, 3 * C, generator=g, device=dev) * 0.5).bfloat16()
     do = (torch.randn(nb * L, C, generator=g, device=dev) * 0.1).bfloat16()
     o, lse = ops.attn_fwd(qkv, nf, L, heads, True)
