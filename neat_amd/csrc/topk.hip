@@ -1000,7 +1000,7 @@ extern "C" int neat_topk_rows(const float* scores, long ld_row, long ld_col, int
     // the fast tier, then the exact tier on the rows it flagged (none at all when k <= SHORT_M)
     int grid = cdiv(R, 4);
     grid = grid > 8192 ? 8192 : grid;
-    const int xgrid = R > 16384 ? 16384 : R;                          // exact tier: a block per row
+    const int xgrid = R > 2048 ? 2048 : R;                            // exact tier: blocks stride over the rows and take the flagged ones
     if (ld_col == 1) {
         const bool vec = ((uintptr_t)scores % 16 == 0) && (ld_row % 4 == 0);
         const int nv = cdiv(Ncol >> 2, 64);                               // 16-B loads per lane that hold a whole row
