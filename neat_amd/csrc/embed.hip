@@ -21,15 +21,25 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tokens, const float
 }
 
 // ---- text.argmax(dim=-1) (reference open_clip/transformer.py:555-558); first maximum wins ----
-__global__ void eot_index_kernel(const int64_t* __restrict__ tokens, int32_t* __restrict__ eot, int nseq, int L) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per sequence: coalesced 8-B loads, then a butterfly arg-max that keeps the lowest position on ties
+__global__ __launch_bounds__(256) void eot_index_kernel(const int64_t* __restrict__ tokens, int32_t* __restrict__ eot, int nseq, int L) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= nseq) return;
     const int64_t* t = tokens + (long)s * L;
-    int64_t best = t[0];
-    int bi = 0;
-    for (int l = 1; l < L; ++l)
-        if (t[l] > best) { best = t[l]; bi = l; }
-    eot[s] = bi;
+    int64_t best = INT64_MIN;
+    int bi = 0x7fffffff;
+    for (int l = lane; l < L; l += 64) {
+        const int64_t v = t[l];
+        if (bi == 0x7fffffff || v > best) { best = v; bi = l; }   // l ascending per lane: first max kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) eot[s] = bi;
 }
 
 // ---- packed ("varlen") text batches -------------------------------------------------------------------
@@ -292,7 +302,7 @@ extern "C" int neat_embed_fwd(const int64_t* tokens, const float* tok_emb, const
 extern "C" int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int L, void* stream) {
     NEAT_REQUIRE(tokens && eot, NEAT_ERR_ARG, "neat_eot_index: null pointer");
     NEAT_REQUIRE(nseq > 0 && L > 0, NEAT_ERR_SHAPE, "neat_eot_index: bad shape");
-    hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(nseq, 128)), dim3(128), 0, (hipStream_t)stream, tokens, eot, nseq, L);
+    hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream, tokens, eot, nseq, L);
     NEAT_LAUNCH_CHECK("neat_eot_index");
     return NEAT_OK;
 }
