@@ -965,7 +965,13 @@ extern "C" int neat_gemm_bf16_t256_gelu_rows(const uint16_t* A, const uint16_t* 
 extern "C" int neat_gemm_prefers_t256(int M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || !t256_shape_ok(N, K)) return 0;
     const bool store_only = epilogue == NEAT_EPI_BF16 || epilogue == NEAT_EPI_BIAS_GELU || epilogue == NEAT_EPI_BIAS_BF16;
-    if (!store_only && (long)N * K < 768L * 3072) return 0;
+    // epilogues that load as much as they store: the fp32 residual one moves to tile256 from N = 768 on (measured at
+    // 768 x 768: 170 vs 184 us; at N = 512 the panel kernel wins, 103 vs 112-123 us and 234 vs 255 us), GELU' from 768 x 3072 on
+    if (epilogue == NEAT_EPI_BIAS_RES_F32 || epilogue == NEAT_EPI_F32) {
+        if (N < 768) return 0;
+    } else if (!store_only && (long)N * K < 768L * 3072) {
+        return 0;
+    }
     const long units = (long)cdiv(M, 256) * (N / 256);
     const int cus = num_cus();
     const long rounds = (units + cus - 1) / cus;
