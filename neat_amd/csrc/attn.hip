@@ -3,9 +3,9 @@
 // causal mask :655-661) and its autograd backward.  head_dim is 64 for every CLIP ViT config.
 //
 // The whole score matrix of a head lives in MFMA accumulators (L <= 272), so there is no online-softmax
-// rescaling and no HBM round trip for S/P.  Short sequences (L <= 80: text, ViT-B/32 vision) use three
-// wavefronts per (sequence, head) over LDS-staged row-major tiles, forward and backward; longer vision
-// sequences use one wavefront per (sequence, head) (forward only).
+// rescaling and no HBM round trip for S/P.  One workgroup per (sequence, head) over LDS-staged row-major tiles: three
+// wavefronts for short sequences (L <= 80: text, ViT-B/32 vision; forward and backward), nine for the longer vision
+// sequences (L <= 272, forward only).
 //
 // Orientation trick (guide §3 "accumulator tile as the next MFMA's operand"): scores are computed
 // TRANSPOSED, S^T = K.Q^T, so the accumulator of v_mfma_f32_16x16x32_bf16 holds for one query
@@ -18,39 +18,7 @@
 
 namespace neat {
 
-constexpr int AT_THREADS = 256;
-constexpr int AT_WAVES = 4;
 constexpr int HD = 64;
-
-// 16-B fragment load of 8 consecutive head-dim elements of row `row` (clamped to < L)
-__device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, long ld, int row, int L, int dofs) {
-    row = row < L ? row : L - 1;
-    return *reinterpret_cast<const bf16x8*>(base + (long)row * ld + dofs);
-}
-
-// stage X^T into LDS: T[d][key] (row pitch ldt elements), zero for key >= L
-__device__ __forceinline__ void stage_transposed(const bf16_t* base, long ld, int L, int LP, bf16_t* T, int ldt,
-                                                 int lane) {
-    for (int idx = lane; idx < LP * 8; idx += 64) {
-        const int key = idx >> 3, ch = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < L) v = *reinterpret_cast<const uint4*>(base + (long)key * ld + ch * 8);
-        bf16_t* dst = T + (ch * 8) * ldt + key;
-        dst[0 * ldt] = (bf16_t)(v.x & 0xffff); dst[1 * ldt] = (bf16_t)(v.x >> 16);
-        dst[2 * ldt] = (bf16_t)(v.y & 0xffff); dst[3 * ldt] = (bf16_t)(v.y >> 16);
-        dst[4 * ldt] = (bf16_t)(v.z & 0xffff); dst[5 * ldt] = (bf16_t)(v.z >> 16);
-        dst[6 * ldt] = (bf16_t)(v.w & 0xffff); dst[7 * ldt] = (bf16_t)(v.w >> 16);
-    }
-}
-
-// A-operand fragment of T (rows = d) for the k-step that covers 16-wide tiles ta and tb of the summed
-// index: elements 0..3 <- T[d][ta*16 + 4*fq + 0..3], 4..7 <- T[d][tb*16 + 4*fq + 0..3]
-__device__ __forceinline__ bf16x8 tfrag(const bf16_t* T, int ldt, int d, int ta, int tb, int fq) {
-    const uint2 lo = *reinterpret_cast<const uint2*>(T + d * ldt + ta * 16 + fq * 4);
-    const uint2 hi = *reinterpret_cast<const uint2*>(T + d * ldt + tb * 16 + fq * 4);
-    uint4 r = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    return __builtin_bit_cast(bf16x8, r);
-}
 
 __device__ __forceinline__ bf16x8 pack_acc2(const f32x4& a, const f32x4& b) {
     uint4 r = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
@@ -64,96 +32,6 @@ __device__ __forceinline__ float xor_max_16_32(float v) {
 __device__ __forceinline__ float xor_sum_16_32(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
-}
-
-template <int NT>
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
-                                                              bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                              int nseq, int L, int heads, int flags) {
-    const int causal = flags & 1;
-    constexpr int LP = NT * 16;
-    constexpr int LDT = LP + 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int C = heads * HD;
-    const long ld = 3L * C;
-    const int total = nseq * heads;
-    int item = blockIdx.x * AT_WAVES + wave;
-    const bool live = item < total;
-    if (!live) item = total - 1;
-    const int s = item / heads, h = item - s * heads;
-    const int part = (flags & 2) ? HD : C;                      // distance between the q, k and v pieces of one head
-    const bf16_t* qb = qkv + (long)s * L * ld + ((flags & 2) ? 3 * h * HD : h * HD);
-    const bf16_t* kb = qb + part;
-    const bf16_t* vb = qb + 2 * part;
-    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem) + (long)wave * HD * LDT;
-    stage_transposed(vb, ld, L, LP, Vt, LDT, lane);
-    __syncthreads();
-    const float scale = 0.125f;  // 1/sqrt(64)
-
-    for (int qt = 0; qt < NT; ++qt) {
-        const int q0 = qt * 16;
-        if (q0 >= L) break;
-        const int query = q0 + fr;
-        const bf16x8 qf0 = gfrag(qb, ld, query, L, fq * 8);
-        const bf16x8 qf1 = gfrag(qb, ld, query, L, 32 + fq * 8);
-        const int nkt = causal ? qt + 1 : NT;
-        f32x4 st[NT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kt < nkt) {
-                const bf16x8 kf0 = gfrag(kb, ld, kt * 16 + fr, L, fq * 8);
-                const bf16x8 kf1 = gfrag(kb, ld, kt * 16 + fr, L, 32 + fq * 8);
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, st[kt], 0, 0, 0);
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, st[kt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fq * 4 + r;
-                const bool ok = kt < nkt && key < L && (!causal || key <= query);
-                st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
-            }
-        }
-        mx = xor_max_16_32(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[kt][r] = __expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
-                sum += st[kt][r];
-            }
-        sum = xor_sum_16_32(sum);
-        if (lse && live && fq == 0 && query < L) lse[((long)s * heads + h) * L + query] = mx + __logf(sum);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < (NT + 1) / 2; ++ks) {
-            if (2 * ks < nkt) {
-                const int ta = 2 * ks, tb = (2 * ks + 1 < NT) ? 2 * ks + 1 : 2 * ks;
-                f32x4 hi = (2 * ks + 1 < NT) ? st[tb] : f32x4{0.f, 0.f, 0.f, 0.f};
-                const bf16x8 pf = pack_acc2(st[ta], hi);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 vf = tfrag(Vt, LDT, dt * 16 + fr, ta, tb, fq);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
-                }
-            }
-        }
-        if (live && query < L) {
-            const float inv = 1.0f / sum;
-            bf16_t* orow = out + ((long)s * L + query) * C + h * HD;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<uint2*>(orow + dt * 16 + fq * 4) =
-                    make_uint2(pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv));
-        }
-    }
 }
 
 // ---- backward: one 192-thread workgroup (3 wavefronts) per (sequence, head) ----
@@ -195,14 +73,14 @@ __device__ __forceinline__ int snake_owner(int rank) {
 // Stage NW row-major [LP x 64] bf16 tiles (Q|K|V at column offsets 0, C, 2C of qkv; tile 3 = dO) into LDS with
 // pitch AB_PITCH.  U independent 16-B loads per thread are issued before the first LDS store, so that a
 // workgroup has its whole tile set in flight at once (rows >= L are zero-filled).
-template <int NW, int U, int LP>
+template <int NW, int U, int LP, int NTHR = AB_THREADS>
 __device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long ld, int part, const bf16_t* dob, int dld, int L) {
     constexpr int total = LP * 8 * NW;
-    for (int base = 0; base < total; base += U * AB_THREADS) {
+    for (int base = 0; base < total; base += U * NTHR) {
         uint4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int idx = base + u * AB_THREADS + threadIdx.x;
+            const int idx = base + u * NTHR + threadIdx.x;
             const int which = idx / (LP * 8);
             const int rem = idx - which * (LP * 8);
             const int row = rem >> 3, ch = rem & 7;
@@ -213,7 +91,7 @@ __device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int idx = base + u * AB_THREADS + threadIdx.x;
+            const int idx = base + u * NTHR + threadIdx.x;
             const int which = idx / (LP * 8);
             const int rem = idx - which * (LP * 8);
             const int row = rem >> 3, ch = rem & 7;
@@ -222,12 +100,14 @@ __device__ __forceinline__ void stage_tiles(bf16_t* dst, const bf16_t* qb, long 
     }
 }
 
-// ---- forward for short sequences (NT <= 5: text L = 77, ViT-B/32 vision L = 50): same 3-wave, LDS-staged
-// structure as the backward.  Q, K, V of one (sequence, head) are staged once, row-major, with coalesced 16-B
+// ---- forward: same LDS-staged structure as the backward.  NT <= 5 (text L = 77, ViT-B/32 vision L = 50): 3 waves per
+// (sequence, head).  NT = 13 / 17 (ViT-B/16 L = 197, ViT-L/14 L = 257: the gallery encode): 9 waves, two query tiles each, the
+// three 39-KB images of one (sequence, head) in LDS -- this replaced a one-wave-per-head kernel that read its K fragments
+// from global memory 17 times over and staged V^T with scalar LDS stores (867 us per layer at ViT-L/14, 250 images).  Q, K, V of one (sequence, head) are staged once, row-major, with coalesced 16-B
 // loads; V^T fragments come from ds_read_b64_tr_b16; the O tile goes back through LDS (the wave's own Q rows)
 // so that the output leaves as whole 128-B rows, 16 B per lane.
-template <int NT>
-__global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv,
+template <int NT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv,
                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
                                                                const int32_t* __restrict__ cu, int nseq, int Lmax,
                                                                int heads, int flags) {
@@ -250,12 +130,14 @@ __global__ __launch_bounds__(AB_THREADS) void attn_fwd3_kernel(const bf16_t* __r
     const int part = (flags & 2) ? HD : C;                      // head-major qkv: [row][head][q|k|v][64]
     const bf16_t* qb = qkv + r0 * ld + ((flags & 2) ? 3 * h * HD : h * HD);
 
-    stage_tiles<3, (LP * 8 * 3 + AB_THREADS - 1) / AB_THREADS, LP>(Qs, qb, ld, part, nullptr, 0, L);
+    constexpr int NTHR = NWV * 64;
+    constexpr int SU = NT <= 5 ? (LP * 8 * 3 + NTHR - 1) / NTHR : 6;   // 16-B loads in flight per thread and pass
+    stage_tiles<3, SU, LP, NTHR>(Qs, qb, ld, part, nullptr, 0, L);
     __syncthreads();
     const float scale = 0.125f;  // 1/sqrt(64)
 
     for (int rank = 0; rank < NT; ++rank) {
-        if (snake_owner(rank) != wave) continue;
+        if ((NWV == AB_WAVES ? snake_owner(rank) : rank % NWV) != wave) continue;
         const int qt = causal ? NT - 1 - rank : rank;   // causal: heaviest tile first
         const int q0 = qt * 16;
         if (q0 >= L) continue;
@@ -507,22 +389,15 @@ static inline int attn_nt(int L) {
 }
 
 template <int NT>
-static int launch_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int nseq, int L, int heads, int causal,
-                      hipStream_t s) {
-    constexpr size_t lds = (size_t)AT_WAVES * HD * (NT * 16 + 8) * 2;
-    static unsigned long long attr_done = 0;                    // per template instance, one bit per device
-    if (int rc = ensure_dynamic_lds((const void*)attn_fwd_kernel<NT>, (int)lds, &attr_done, "attn_fwd attr")) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(cdiv((long)nseq * heads, AT_WAVES)), dim3(AT_THREADS), lds, s, qkv,
-                       out, lse, nseq, L, heads, causal);
-    NEAT_LAUNCH_CHECK("neat_attn_fwd");
-    return NEAT_OK;
-}
-
-template <int NT>
 static int launch_fwd3(const uint16_t* qkv, uint16_t* out, float* lse, const int32_t* cu, int nseq, int L, int heads,
                        int causal, hipStream_t s) {
+    constexpr int NWV = NT <= 5 ? AB_WAVES : 9;
     constexpr size_t lds = (size_t)3 * NT * 16 * AB_PITCH * 2;
-    hipLaunchKernelGGL(attn_fwd3_kernel<NT>, dim3(nseq * heads), dim3(AB_THREADS), lds, s, qkv, out, lse, cu, nseq, L,
+    if (lds > 64 * 1024) {
+        static unsigned long long attr_done = 0;                // per template instance, one bit per device
+        if (int rc = ensure_dynamic_lds((const void*)attn_fwd3_kernel<NT, NWV>, (int)lds, &attr_done, "attn_fwd attr")) return rc;
+    }
+    hipLaunchKernelGGL((attn_fwd3_kernel<NT, NWV>), dim3(nseq * heads), dim3(NWV * 64), lds, s, qkv, out, lse, cu, nseq, L,
                        heads, causal);
     NEAT_LAUNCH_CHECK("neat_attn_fwd");
     return NEAT_OK;
@@ -557,8 +432,8 @@ extern "C" int neat_attn_fwd(const uint16_t* qkv, uint16_t* out, float* lse, con
         case 3: return launch_fwd3<3>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 4: return launch_fwd3<4>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         case 5: return launch_fwd3<5>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
-        case 13: return launch_fwd<13>(qkv, out, lse, nseq, L, heads, causal, s);
-        case 17: return launch_fwd<17>(qkv, out, lse, nseq, L, heads, causal, s);
+        case 13: return launch_fwd3<13>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
+        case 17: return launch_fwd3<17>(qkv, out, lse, cu_seqlens, nseq, L, heads, causal, s);
         default: return set_error(NEAT_ERR_SHAPE, "neat_attn_fwd: sequence length %d > 272 unsupported", L);
     }
 }
