@@ -51,7 +51,8 @@ int neat_ln_fwd(const float* x, const float* gamma, const float* beta, uint16_t*
 /* Backward.  dy bf16 [rows,cols]; dres f32 (may be NULL) is the residual-branch gradient that is added
  * to the LN data gradient: dx = dres + LN'(dy).  dx_f32 / dx_bf16 outputs (either may be NULL; dx_f32
  * may alias dres).  partial f32 [nblk, 2, cols] receives per-block sums of dy*xhat and dy
- * (nblk = neat_ln_bwd_blocks(rows)); pass NULL to skip parameter gradients (ln_final). */
+ * (nblk = neat_ln_bwd_blocks(rows)); pass NULL to skip parameter gradients (ln_final).  With BOTH dx outputs NULL (and
+ * partial given) only the parameter sums are formed: the first block's ln_1 of a tower whose embeddings are frozen. */
 int neat_ln_bwd_blocks(int rows);
 int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
                 const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16, float* partial,

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
                 s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
             }
         }
+        if (!dxf && !dxb) continue;                              // parameter gradients only (uniform for the whole grid)
         const float m1 = wave_sum(s1) * inv;
         const float m2 = wave_sum(s2) * inv;
 #pragma unroll
@@ -276,7 +277,8 @@ extern "C" int neat_ln_bwd_blocks(int rows) {
 extern "C" int neat_ln_bwd(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
                            const float* rstd, const float* dres, float* dx_f32, uint16_t* dx_bf16,
                            float* partial, int rows, int cols, void* stream) {
-    NEAT_REQUIRE(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), NEAT_ERR_ARG, "neat_ln_bwd: null pointer");
+    NEAT_REQUIRE(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16 || partial), NEAT_ERR_ARG,
+                 "neat_ln_bwd: null pointer (at least one of dx_f32, dx_bf16, partial)");
     NEAT_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 1024, NEAT_ERR_SHAPE,
                  "neat_ln_bwd: rows=%d cols=%d unsupported (cols %% 4 == 0, <= 1024)", rows, cols);
     hipStream_t s = (hipStream_t)stream;

@@ -70,10 +70,12 @@ class Stack:
         return x
 
     def backward(self, dxf, dxb, nseq: int, L: int, saved: list, grads: List[Dict[str, torch.Tensor]],
-                 accumulate: bool, cu=None):
+                 accumulate: bool, cu=None, need_input_grad: bool = True):
         """dxf fp32 / dxb bf16 [M, C]: gradient w.r.t. the stack output for the FIRST nseq sequences of the saved
         forward (M = nseq*L rows, or cu[nseq] rows of a packed batch).  grads[i] = dict(ln1_w, ln1_b, ln2_w,
-        ln2_b) receive d(gamma), d(beta)."""
+        ln2_b) receive d(gamma), d(beta).  need_input_grad=False: nothing below the stack is trainable (the frozen
+        embeddings of the text tower), so the first block's ln_1 only reduces its parameter gradients; the gradient with
+        respect to the stack input is neither formed nor written and (None, None) is returned."""
         M = dxf.shape[0]
         C = dxf.shape[1]
         # the per-block partial sums of d(gamma), d(beta) of all 2*layers LayerNorms are reduced by ONE launch at the end
@@ -89,8 +91,9 @@ class Stack:
             do, _ = ops.gemm(dxb, w.wT["o"], lib.EPI_BF16)
             dqkv = ops.attn_bwd(s["qkv"], do, s["lse"], nseq, L, self.heads, self.causal, cu=cu, head_major=True)
             dy1, _ = ops.gemm(dqkv, w.wT["qkv"], lib.EPI_BF16)
-            dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=dxf, inplace_res=True,
-                                  partial=parts[2 * j + 1])
+            last = j == nl - 1 and not need_input_grad
+            dxf, dxb = ops.ln_bwd(dy1, s["x0"][:M], w.ln1_w, s["mu1"], s["rs1"], dres=None if last else dxf,
+                                  inplace_res=not last, want_f32=not last, want_bf16=not last, partial=parts[2 * j + 1])
             dsts.append((g["ln1_w"], g["ln1_b"]))
         ops.ln_bwd_finalize_batched(parts, dsts, accumulate=accumulate)
         return dxf, dxb
@@ -148,7 +151,7 @@ class TextTower:
         dxb = torch.zeros(rows, self.C, dtype=bf16, device=dfeat.device)
         ops.pool_proj_bwd(dfeat.contiguous(), ctx["feat"], ctx["head"], self.lnf_w, self.proj, ctx["eot"], n,
                           L if cu is None else 0, ctx["normalize"], dxf, dxb)
-        self.stack.backward(dxf, dxb, n, L, ctx["saved"], grads, accumulate, cu=cu)
+        self.stack.backward(dxf, dxb, n, L, ctx["saved"], grads, accumulate, cu=cu, need_input_grad=False)
 
 
 class VisionTower:

@@ -55,6 +55,15 @@ def test_ln_fwd_bwd(rows, cols):
     assert rel_l2(dg.cpu(), 2 * dg_ref) < 1e-5
     dxf2, _ = ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, want_bf16=False)
     assert rel_l2(dxf2.cpu(), dx_ref) < 1e-5
+    # parameter gradients only (both dx outputs NULL: the first block's ln_1 of a tower with frozen embeddings): same sums
+    dg3, db3 = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    none = ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, want_f32=False, want_bf16=False, dgamma=dg3, dbeta=db3)
+    assert none == (None, None)
+    dg4, db4 = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, dgamma=dg4, dbeta=db4)
+    assert torch.equal(dg3, dg4) and torch.equal(db3, db4)
+    with pytest.raises(RuntimeError, match="at least one"):
+        ops.ln_bwd(dy.to(DEV), x.to(DEV), gam.to(DEV), mu, rs, want_f32=False, want_bf16=False)
 
 
 def test_ln_is_deterministic():
