@@ -9,6 +9,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --skip-gallery-encode --no-packed > $O/pmc_$c.log 2>&1 || exit 1
   python3 tools/summarize_pmc.py $(ls $O/pmc_$c/*/*counter_collection.csv | head -1) $O/bench_pmc_$(echo $c | tr A-Z a-z).csv || exit 1
 done
+# matrix-pipe utilisation per kernel inside the step
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --skip-gallery-encode --no-packed > $O/pmc_mfma.log 2>&1 || exit 1
+python3 tools/summarize_pmc.py $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) $O/bench_pmc_mfma_busy.csv || exit 1
+rm -rf $O/pmc_mfma
 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_auto.txt
 NEAT_GEMM=panel timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_panel.txt
 NEAT_GEMM=t256 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/gemm_shapes_t256.txt
