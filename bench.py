@@ -55,6 +55,9 @@ def parse():
                          "says so; this is not the BASELINE configuration)")
     ap.add_argument("--no-packed", action="store_true",
                     help="skip the extra (non-headline) measurement with model.pack_tokens = True")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only form the process group, add up their ranks and print one JSON line: checks the "
+                         "self-launch path of --gpus N without touching a GPU (tests/test_host_logic.py)")
     ap.add_argument("--skip-gallery-encode", action="store_true",
                     help="profiling aid: random unit-norm gallery features instead of Phase A, so that a "
                          "rocprofv3 summary holds text-tower launches only")
@@ -77,13 +80,51 @@ def _dbg(msg):
         print(f"[bench rank {os.environ.get('RANK', 0)}] {msg}", file=sys.stderr, flush=True)
 
 
+def launch_ranks(a):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks ourselves, one per GPU, as
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` (the reference's
+    intent: one process per GPU, rows = tta_total_bs // world, main_TTA.py:245-256).  This process is only the parent:
+    it never touches a GPU (``torch.cuda.device_count()`` does not initialise one on this stack), relays the children's
+    output -- rank 0's JSON line included -- and exits with the launcher's status."""
+    import socket
+    import subprocess
+    backend = os.environ.get("NEAT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and not a.launcher_selftest and ndev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs (one RCCL rank per GPU), found {ndev}; "
+              f"no line is printed for a run that did not happen", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL needs dmabuf IPC on this host driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(a, rank, world):
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    x = torch.tensor([float(rank)])
+    dist.all_reduce(x)
+    if rank == 0:
+        print(json.dumps(dict(selftest=True, n_gpus=world, rank_sum=float(x.item()))))
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if a.launcher_selftest:
+        return launcher_selftest(a, rank, world)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)          # rehearsal of N ranks on fewer GPUs (NEAT_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)

@@ -1,6 +1,6 @@
 """The library's own RCCL communicator (C ABI ``neat_comm_*``, ``include/neat_hip.h``) from Python.
 
-Opt-in: ``NEAT_COMM=rccl`` makes the data-parallel step (``train_TTA._gather_into`` / ``_reduce_sum``) issue its
+Opt-in: ``NEAT_COMM=rccl`` makes the data-parallel step (``train_TTA._gather_into``) issue its
 collectives through ``libneat_hip.so`` instead of ``torch.distributed``; the default stays ``torch.distributed`` on the
 ``nccl`` backend, which IS RCCL on ROCm.  The communicator's id travels through the existing process group (any backend),
 so the launcher (``torchrun``: one process per GPU) does not change.  Stands in for the reference's
@@ -36,14 +36,32 @@ def init(id_bytes: bytes, world: int, rank: int):
 
 
 def init_from_process_group():
-    """Rank 0 draws the id, the existing torch.distributed group broadcasts it, every rank joins."""
+    """Rank 0 draws the id, the existing torch.distributed group broadcasts it, every rank joins.
+
+    Every rank first probes what it needs alone (the library loads, RCCL resolves, rank 0 can draw an id) and the ranks
+    exchange an ok flag through the process group BEFORE the id broadcast: a rank that cannot go on makes ALL ranks raise
+    together instead of leaving the others blocked in the broadcast."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
     t = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        t = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).clone()
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
+    err = ""
+    try:
+        lib.load()
+        ident = unique_id()                      # resolves RCCL with dlopen on every rank; only rank 0's id is used
+        if rank == 0:
+            t = torch.frombuffer(bytearray(ident), dtype=torch.uint8).clone()
+    except Exception as e:                       # noqa: BLE001 -- reported below, on every rank
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0 if err else 1], dtype=torch.int64)
+    oks = torch.empty(world, dtype=torch.int64)
+    if on_gpu:
+        ok, oks, t = ok.cuda(), oks.cuda(), t.cuda()
+    dist.all_gather_into_tensor(oks, ok)
+    bad = [r for r, v in enumerate(oks.tolist()) if not v]
+    if bad:
+        raise RuntimeError(f"comm.init_from_process_group: ranks {bad} cannot create the RCCL communicator"
+                           + (f" (this rank: {err})" if err else ""))
     dist.broadcast(t, 0)
     init(bytes(t.cpu().tolist()), world, rank)
 

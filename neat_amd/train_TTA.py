@@ -48,7 +48,7 @@ def tta_loss(text_feat, pos_text_feat, inv_text_feat, coarse_img_feat, T1, T2):
 
 
 # NEAT_FORCE_COLLECTIVES=1: run every collective of the data-parallel step even at world size 1 (a one-GPU rehearsal of the
-# RCCL call path: process group, all_gather of padded row shards, all_reduce of the flat LN gradient)
+# RCCL call path: process group, all-gather of padded row shards, all-gather + ordered sum of the flat LN gradient)
 FORCE_COLLECTIVES = os.environ.get("NEAT_FORCE_COLLECTIVES", "") == "1"
 
 
@@ -88,18 +88,6 @@ def _gather_into(out, x):
         out.copy_(host)
     else:
         dist.all_gather_into_tensor(out, x.contiguous())
-
-
-def _reduce_sum(x):
-    if x.dtype == torch.float32 and x.is_contiguous() and _own_comm(x):
-        from . import comm
-        comm.all_reduce_sum_(x)
-    elif _host_staged(x):
-        host = x.cpu()
-        dist.all_reduce(host)
-        x.copy_(host)
-    else:
-        dist.all_reduce(x)
 
 
 def _all_gather_rows(x, n_total: int, world: int):
@@ -187,9 +175,9 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
     coarse, idx, S = ops.coarse_align(t, p, n, gallery)
     if world > 1 or FORCE_COLLECTIVES:
         if global_rows is None:
-            B = torch.tensor([Bl], device=t.device)
-            _reduce_sum(B)
-            B = int(B.item())
+            counts = torch.empty(world, dtype=torch.int64, device=t.device)
+            _gather_into(counts, torch.tensor([Bl], dtype=torch.int64, device=t.device))
+            B = int(counts.sum().item())
         else:
             B = int(global_rows)
         row0 = _shard(B, world, rank)[0]
@@ -215,10 +203,19 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
             torch.sum(gathered, dim=0, out=buf)
             losses[1:].copy_(buf[-2:])
         else:
-            for g in grads:
-                for x in g.values():
-                    _reduce_sum(x)
-            _reduce_sum(losses[1:])          # sr / triplet are sums over local rows; entropy is already global
+            # any other optimizer over the same parameters (torch.optim.AdamW ...): the per-parameter .grad tensors and
+            # the two row-summed loss terms are copied into one flat scratch and take the SAME route -- one all-gather,
+            # a sum in rank order, copies back.  No all_reduce on the step (49 of them per step before; what
+            # GatherLayer's all_reduce in the reference's unused src/ddp.py:29-56 would have done per feature tensor).
+            flat = [x for g in grads for x in g.values()]
+            sizes = [x.numel() for x in flat]
+            buf = torch.cat([x.reshape(-1) for x in flat] + [losses[1:].reshape(-1)])
+            gathered = torch.empty(world, buf.numel(), dtype=buf.dtype, device=buf.device)
+            _gather_into(gathered.view(-1), buf)
+            total = torch.sum(gathered, dim=0)
+            for x, piece in zip(flat, torch.split(total[:-2], sizes)):
+                x.copy_(piece.view_as(x))
+            losses[1:].copy_(total[-2:])          # sr / triplet are sums over local rows; entropy is already global
     optimizer.step()
     optimizer.zero_grad()
     return losses, idx, S
@@ -237,6 +234,10 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     if getattr(args, "tta_only_visual", False):
         return score_matrix_i2t, score_matrix_t2i      # reference: `pass` (train_TTA.py:113-114)
 
+    if world > 1 or FORCE_COLLECTIVES:
+        from . import comm
+        if comm.ENABLED and torch.device(device).type == "cuda" and not comm.ready():
+            comm.init_from_process_group()        # here, not inside the first gather: all ranks fail or go on together
     # which rows does this rank see?  (raises on a sampler that does not match the process group)
     text_sharded = _loader_is_sharded(data_loader_text, world, rank, "text")
     image_sharded = _loader_is_sharded(data_loader_image, world, rank, "image")

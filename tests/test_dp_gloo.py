@@ -88,7 +88,7 @@ class _OracleTower:
 
 class _FlatGradAdamW(torch.optim.AdamW):
     """torch's AdamW with the gradient layout of neat_amd.optim.AdamW (which needs a GPU): every .grad is a view of
-    ``grad_buf[:n]``, two spare floats behind -- the layout tta_step's single all-reduce relies on."""
+    ``grad_buf[:n]``, two spare floats behind -- the layout tta_step's single all-gather relies on."""
 
     def __init__(self, params, **kw):
         params = list(params)
@@ -132,6 +132,10 @@ def _worker(rank, world, port, out, B=None, flat=False):
         G = torch.nn.functional.normalize(torch.randn(NIMG, 512, generator=gen), dim=-1)
         lo, hi = T._shard(B, world, rank)
         local = [x[lo:hi].contiguous() for x in toks]
+
+        def _no_all_reduce(*a, **k):
+            raise AssertionError("dist.all_reduce on the TTA step: both optimizer branches use one all-gather + ordered sum")
+        dist.all_reduce = _no_all_reduce
         for _ in range(STEPS):
             losses, idx, S = T.tta_step(model, opt, local, G, T1, T2, world, rank, global_rows=B if flat else None)
         S_all = T._all_gather_rows(S, B, world)
@@ -162,9 +166,11 @@ def test_shard_covers_rows_in_order():
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("B,flat", [(7, False), (8, True)])
 def test_tta_step_world2_matches_single_process_oracle(tmp_path, B, flat):
-    """(7, False): uneven shards 4+3 (padded all_gather), per-tensor gradient all-reduces, row count by collective.
-    (8, True): even shards (all_gather_into_tensor), ONE all-reduce over grad_buf (gradients + two loss terms), the
-    caller passes the global row count -- the path bench.py and train_one_epoch take with neat_amd.optim.AdamW."""
+    """(7, False): uneven shards 4+3 (padded all_gather), plain torch.optim.AdamW -- the per-parameter gradients travel
+    through one flat scratch (one all-gather + ordered sum, no all_reduce), row count by collective.
+    (8, True): even shards (all_gather_into_tensor), ONE all-gather over grad_buf (gradients + two loss terms), the
+    caller passes the global row count -- the path bench.py and train_one_epoch take with neat_amd.optim.AdamW.
+    Either way the worker makes dist.all_reduce raise for the duration of the steps."""
     from neat_amd import synth
     from oracle import neat_oracle as O
 

@@ -164,3 +164,38 @@ def test_pretrained_checkpoint_needs_an_explicit_quick_gelu(tmp_path):
         oc.create_model("neat-tiny", pretrained=str(ck), device="cpu")
     m = oc.create_model("neat-tiny", pretrained=str(ck), device="cpu", force_quick_gelu=True)
     assert torch.equal(m.text_projection.detach(), sd["text_projection"])
+
+
+# ------------------------------------------------------------------ bench.py starts its own ranks
+def _run_bench(*argv, env_extra=None):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=240)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks under torch.distributed.run, rank 0's one JSON
+    line relayed, the child's status returned (reference intent: main_TTA.py:245-256, one process per GPU)."""
+    import json
+    r = _run_bench("--gpus", "2", "--launcher-selftest")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == dict(selftest=True, n_gpus=2, rank_sum=1.0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
+def test_bench_gpus_n_refuses_without_n_gpus():
+    """Fewer GPUs than ranks: a clear message and a non-zero status, never an `n_gpus: 1` line."""
+    r = _run_bench("--gpus", "2")
+    assert r.returncode == 2
+    assert "needs 2 visible GPUs" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
