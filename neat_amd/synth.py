@@ -73,9 +73,11 @@ def _randn(seed, key, shape, std=1.0, mean=0.0):
     return x
 
 
-def _block_keys(prefix: str, width: int, layers: int, seed: int, sd: dict, mlp_ratio: float = 4.0):
-    """One transformer stack; std values follow the text-tower init (transformer.py:634-641)."""
-    proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+def _block_keys(prefix: str, width: int, layers: int, seed: int, sd: dict, mlp_ratio: float = 4.0,
+                branch_gain: float = 1.0):
+    """One transformer stack; std values follow the text-tower init (transformer.py:634-641).  ``branch_gain`` scales the
+    two matrices that write into the residual stream (out_proj, c_proj)."""
+    proj_std = (width ** -0.5) * ((2 * layers) ** -0.5) * branch_gain
     attn_std = width ** -0.5
     fc_std = (2 * width) ** -0.5
     hidden = int(width * mlp_ratio)
@@ -97,7 +99,7 @@ def _block_keys(prefix: str, width: int, layers: int, seed: int, sd: dict, mlp_r
         sd[p + "mlp.c_proj.bias"] = _randn(seed, p + "mlp.c_proj.bias", (width,), 0.02)
 
 
-def synth_state_dict(model_name: str, seed: int = 0) -> Dict[str, torch.Tensor]:
+def synth_state_dict(model_name: str, seed: int = 0, branch_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded fp32 CLIP weights keyed like an open_clip ``CLIP.state_dict()``.
 
     Each tensor draws from its own generator (seed, key) so the result does not depend on
@@ -119,12 +121,12 @@ def synth_state_dict(model_name: str, seed: int = 0) -> Dict[str, torch.Tensor]:
     for nm in ("ln_pre", "ln_post"):
         sd[f"visual.{nm}.weight"] = _randn(seed, f"visual.{nm}.weight", (vw,), 0.2, 1.0)
         sd[f"visual.{nm}.bias"] = _randn(seed, f"visual.{nm}.bias", (vw,), 0.1)
-    _block_keys("visual.transformer.", vw, v["layers"], seed, sd)
+    _block_keys("visual.transformer.", vw, v["layers"], seed, sd, branch_gain=branch_gain)
 
     tw = t["width"]
     sd["token_embedding.weight"] = _randn(seed, "token_embedding.weight", (t["vocab_size"], tw), 0.3)
     sd["positional_embedding"] = _randn(seed, "positional_embedding", (t["context_length"], tw), 0.05)
-    _block_keys("transformer.", tw, t["layers"], seed, sd)
+    _block_keys("transformer.", tw, t["layers"], seed, sd, branch_gain=branch_gain)
     sd["ln_final.weight"] = _randn(seed, "ln_final.weight", (tw,), 0.2, 1.0)
     sd["ln_final.bias"] = _randn(seed, "ln_final.bias", (tw,), 0.1)
     sd["text_projection"] = _randn(seed, "text_projection", (tw, D), tw ** -0.5)
@@ -159,6 +161,67 @@ def synth_caption_sets(n: int, context_length: int, vocab_size: int, seed: int,
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return tuple(synth_tokens(n, context_length, vocab_size, g, min_len, max_len) for _ in range(4))
+
+
+def _edit_caption(row: torch.Tensor, vocab_size: int, gen: torch.Generator, n_sub: int, insert=()) -> torch.Tensor:
+    """A caption derived from ``row``: n_sub body tokens replaced by random ids, ``insert`` spliced in at a random place
+    (when the context has room).  Integer draws only."""
+    sot, eot = vocab_size - 2, vocab_size - 1
+    L = row.shape[0]
+    l = int(row.argmax())                                   # EOT position
+    body = row[1:l].clone()
+    if n_sub:
+        at = torch.randint(0, len(body), (n_sub,), generator=gen)
+        body[at] = torch.randint(1, sot, (n_sub,), generator=gen)
+    if len(insert) and l + len(insert) < L - 1:
+        at = int(torch.randint(0, len(body) + 1, (1,), generator=gen))
+        body = torch.cat([body[:at], torch.tensor(list(insert), dtype=row.dtype), body[at:]])
+    out = torch.zeros_like(row)
+    out[0] = sot
+    out[1:1 + len(body)] = body
+    out[1 + len(body)] = eot
+    return out
+
+
+def synth_related_caption_sets(n: int, context_length: int, vocab_size: int, seed: int,
+                               min_len: int = 5, max_len: int = 20):
+    """(text, pos, neg, inv) token sets that are RELATED the way NegBench's are (reference
+    data/coco_negated_dataset.py:63-79: a caption, its paraphrase, a caption about what is absent, its negated rewrite):
+    pos = the caption with one token replaced; inv = the caption with a two-token "negation" spliced in and one token
+    replaced; neg = an edit of ANOTHER caption (row (r + n//2) % n).  Unlike ``synth_caption_sets`` (four independent
+    draws) the four features of a row are then correlated like those of a real row."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    text = synth_tokens(n, context_length, vocab_size, g, min_len, max_len)
+    marker = (783, 1000) if vocab_size > 2000 else (7, 11)
+    pos = torch.stack([_edit_caption(text[r], vocab_size, g, 1) for r in range(n)])
+    neg = torch.stack([_edit_caption(text[(r + n // 2) % n], vocab_size, g, 1) for r in range(n)])
+    inv = torch.stack([_edit_caption(text[r], vocab_size, g, 1, marker) for r in range(n)])
+    return text, pos, neg, inv
+
+
+SPREAD_BRANCH_GAIN = 4.0
+
+
+def spread_state_dict(model_name: str, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """The "spread" weights of tests/golden/make_spread_weights.py: the synthetic weights with the residual branches
+    scaled by SPREAD_BRANCH_GAIN (every layer matters, as in a trained tower) and with ``visual.proj`` /
+    ``text_projection`` replaced by the two FITTED matrices stored (as bf16 bit patterns, exact in fp32) in
+    tests/golden/spread_<model>.npz, which place gallery images and captions in a shared space the way a trained CLIP
+    does: features are far from collinear and recall@1 is far from chance."""
+    import os
+
+    import numpy as np
+    sd = synth_state_dict(model_name, seed, branch_gain=SPREAD_BRANCH_GAIN)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        f"spread_{model_name.lower().replace('-', '')}.npz")
+    z = np.load(path)
+    for key in ("visual.proj", "text_projection"):
+        bits = torch.from_numpy(z[key.replace(".", "_")].astype(np.int32)) << 16
+        w = bits.view(torch.float32)
+        assert w.shape == sd[key].shape
+        sd[key] = w.clone()
+    return sd
 
 
 def synth_images(n: int, image_size: int, seed: int) -> torch.Tensor:

@@ -72,14 +72,14 @@ def import_reference():
     return oc, train_TTA, retrieval
 
 
-def build_ref_model(oc, name, seed):
+def build_ref_model(oc, name, seed, spread=False):
     if name == "neat-tiny":
         d = tempfile.mkdtemp()
         with open(os.path.join(d, "neat-tiny.json"), "w") as f:
             json.dump(synth.MODEL_CFGS["neat-tiny"], f)
         oc.add_model_config(d)
     model = oc.create_model(name, pretrained=None, precision="fp32", device="cpu", force_quick_gelu=True)
-    sd = synth.synth_state_dict(name, seed)
+    sd = synth.spread_state_dict(name, seed) if spread else synth.synth_state_dict(name, seed)
     missing = model.load_state_dict(sd, strict=True)   # proves the key layout matches open_clip's
     assert not missing.missing_keys and not missing.unexpected_keys
     return model, sd
@@ -101,9 +101,10 @@ class FakeLoader:
         return iter(self.batches)
 
 
-def make_batches(cfg, n_text, n_image, bs_text, bs_image, data_seed):
+def make_batches(cfg, n_text, n_image, bs_text, bs_image, data_seed, related=False):
     t = cfg["text_cfg"]
-    sets = synth.synth_caption_sets(n_text, t["context_length"], t["vocab_size"], data_seed)
+    sets = (synth.synth_related_caption_sets if related else synth.synth_caption_sets)(
+        n_text, t["context_length"], t["vocab_size"], data_seed)
     images = synth.synth_images(n_image, cfg["vision_cfg"]["image_size"], data_seed + 1)
     g = torch.Generator().manual_seed(data_seed + 2)
     perm_t = torch.randperm(n_text, generator=g)       # reference loader shuffles (data/__init__.py:60)
@@ -205,10 +206,10 @@ def weight_checksums(sd):
 
 
 def case_tta(oc, tt, retrieval, tag, model_name, n_text, n_image, bs_text, bs_image, wseed=0, dseed=1234,
-             store_score=True, store_grads=True):
+             store_score=True, store_grads=True, spread=False):
     cfg = synth.get_cfg(model_name)
-    model, sd = build_ref_model(oc, model_name, wseed)
-    tb, ib = make_batches(cfg, n_text, n_image, bs_text, bs_image, dseed)
+    model, sd = build_ref_model(oc, model_name, wseed, spread=spread)
+    tb, ib = make_batches(cfg, n_text, n_image, bs_text, bs_image, dseed, related=spread)
     with torch.no_grad():
         img_rows = model.encode_image(ib[0][0][:8], normalize=True).clone()
         txt_unnorm = model.encode_text(tb[0][0][:8], normalize=False).clone()
@@ -216,7 +217,7 @@ def case_tta(oc, tt, retrieval, tag, model_name, n_text, n_image, bs_text, bs_im
     out = dict(
         meta=np.array(json.dumps(dict(model=model_name, n_text=n_text, n_image=n_image, bs_text=bs_text,
                                       bs_image=bs_image, wseed=wseed, dseed=dseed, steps=3, lr=2e-4, wd=1e-3,
-                                      T1=0.03, T2=0.07, names=rec["names"], seconds=rec["seconds"],
+                                      T1=0.03, T2=0.07, names=rec["names"], seconds=rec["seconds"], spread=spread,
                                       torch=torch.__version__))),
         wsum=weight_checksums(sd),
         loss_ent=np.array(rec["ent"]), loss_sr=np.array(rec["sr"]), loss_tri=np.array(rec["tri"]),
@@ -335,6 +336,11 @@ def main():
             # container's memory; the only change to the reference is the gallery-buffer width (see above)
             case_tta(oc, tt, retrieval, "vitl14_b128", "ViT-L-14", n_text=128, n_image=32, bs_text=128,
                      bs_image=8, store_score=False, store_grads=True)
+        elif c == "vitb32_spread_b256":
+            # the "spread" weights + related caption sets (tests/golden/make_spread_weights.py, same data seed): features
+            # far from collinear, recall@1 ~0.7 -- the non-degenerate end-to-end fixture
+            case_tta(oc, tt, retrieval, "vitb32_spread_b256", "ViT-B-32", n_text=256, n_image=256, bs_text=256,
+                     bs_image=64, dseed=4321, store_score=True, store_grads=True, spread=True)
         else:
             raise SystemExit(f"unknown case {c}")
 

@@ -21,9 +21,10 @@ def load_golden(tag):
     return d
 
 
-def make_batches(cfg, n_text, n_image, bs_text, bs_image, data_seed):
+def make_batches(cfg, n_text, n_image, bs_text, bs_image, data_seed, related=False):
     t = cfg["text_cfg"]
-    sets = synth.synth_caption_sets(n_text, t["context_length"], t["vocab_size"], data_seed)
+    sets = (synth.synth_related_caption_sets if related else synth.synth_caption_sets)(
+        n_text, t["context_length"], t["vocab_size"], data_seed)
     images = synth.synth_images(n_image, cfg["vision_cfg"]["image_size"], data_seed + 1)
     g = torch.Generator().manual_seed(data_seed + 2)
     perm_t = torch.randperm(n_text, generator=g)

@@ -40,8 +40,8 @@ def _report(tag, d):
     json.dump(allr, open(REPORT, "w"), indent=1)
 
 
-def _model(name, seed):
-    sd = synth.synth_state_dict(name, seed)
+def _model(name, seed, spread=False):
+    sd = synth.spread_state_dict(name, seed) if spread else synth.synth_state_dict(name, seed)
     m = oc.create_model(name, device=DEV)
     m.load_state_dict(sd, strict=True)
     return m, sd
@@ -70,10 +70,11 @@ def _run_hip_manual(tag, packed=False):
     g = load_golden(tag)
     m = g["meta"]
     cfg = synth.get_cfg(m["model"])
-    model, sd = _model(m["model"], m["wseed"])
+    model, sd = _model(m["model"], m["wseed"], spread=m.get("spread", False))
     model.pack_tokens = packed
     np.testing.assert_allclose(weight_checksums(sd), g["wsum"], rtol=1e-9)
-    tb, ib = make_batches(cfg, m["n_text"], m["n_image"], m["bs_text"], m["bs_image"], m["dseed"])
+    tb, ib = make_batches(cfg, m["n_text"], m["n_image"], m["bs_text"], m["bs_image"], m["dseed"],
+                          related=m.get("spread", False))
     out = dict(g=g, m=m, sd=sd, tb=tb, ib=ib)
     with torch.no_grad():
         out["img_rows"] = model.encode_image(ib[0][0][:8].to(DEV), normalize=True).cpu()
@@ -134,7 +135,15 @@ GRAD1_COS_MIN, GRAD1_REL_MAX = 0.999, 0.05
 UPDATE_COS_MIN, UPDATE_REL_MAX = 0.99, 0.15
 
 
-def _update_gate(final, p0, ref_final):
+# The spread weights scale every residual branch by 4: bf16 rounding noise compounds through the twelve layers about four
+# times as fast as with the plain weights (feature cosine 0.99986 instead of 0.99997; test_gradient_error_attribution
+# [spread] splits the gradient error into its forward and backward shares), so the step-1 gradient agrees to ~10 % and
+# the three-step Adam update -- which moves every element by ~lr * sign(g) -- to ~28 %.  Stated bounds for that fixture;
+# the three controls (no step, negated, halved update) still fail them.
+SPREAD_GRAD_GATE, SPREAD_UPDATE_GATE = (0.99, 0.15), (0.93, 0.40)
+
+
+def _update_gate(final, p0, ref_final, cos_min=UPDATE_COS_MIN, rel_max=UPDATE_REL_MAX):
     """(passes, cos, rel, sign-flip fraction) of the parameter update final - p0 against the reference's."""
     up, ref = (final - p0).double(), (torch.as_tensor(ref_final) - p0).double()
     if float(up.norm()) == 0.0:
@@ -142,10 +151,13 @@ def _update_gate(final, p0, ref_final):
     cos = min_cosine(up.view(1, -1), ref.view(1, -1))
     rel = rel_l2(up, ref)
     flips = float((torch.sign(up) != torch.sign(ref)).double().mean())
-    return (cos >= UPDATE_COS_MIN and rel <= UPDATE_REL_MAX), cos, rel, flips
+    return (cos >= cos_min and rel <= rel_max), cos, rel, flips
 
 
-def _check_against_reference(tag, loss_tol, param_tol, packed=False):
+def _check_against_reference(tag, loss_tol, param_tol, packed=False, per_term_tol=None, max_idx_flips=None,
+                             grad_gate=(GRAD1_COS_MIN, GRAD1_REL_MAX), update_gate=(UPDATE_COS_MIN, UPDATE_REL_MAX)):
+    """per_term_tol: gate EVERY loss term (semantics reversion included) relative to itself, SURVEY.md §8(d)'s
+    "each loss term and total rel <= 1e-3"; max_idx_flips: exact bound on coarse-index mismatches."""
     r = _run_hip_manual(tag, packed)
     g, m = r["g"], r["m"]
     rep = {}
@@ -172,11 +184,11 @@ def _check_against_reference(tag, loss_tol, param_tol, packed=False):
     rep["param_rel_final"] = rel_l2(r["final"], g["final_params"])
     p0 = torch.cat([r["sd"][k].flatten() for k in m["names"]])
     ok_update, rep["update_cos"], rep["update_rel"], rep["update_sign_flip_frac"] = _update_gate(
-        r["final"], p0, g["final_params"])
+        r["final"], p0, g["final_params"], *update_gate)
     # controls: the same gate must FAIL for a model that never stepped and for one that stepped the wrong way
-    noop_ok = _update_gate(p0.clone(), p0, g["final_params"])[0]
-    wrong_ok = _update_gate(2 * p0 - torch.from_numpy(g["final_params"]), p0, g["final_params"])[0]
-    half_ok = _update_gate(p0 + 0.5 * (torch.from_numpy(g["final_params"]) - p0), p0, g["final_params"])[0]
+    noop_ok = _update_gate(p0.clone(), p0, g["final_params"], *update_gate)[0]
+    wrong_ok = _update_gate(2 * p0 - torch.from_numpy(g["final_params"]), p0, g["final_params"], *update_gate)[0]
+    half_ok = _update_gate(p0 + 0.5 * (torch.from_numpy(g["final_params"]) - p0), p0, g["final_params"], *update_gate)[0]
     rep["control_gate_passes"] = dict(no_step=noop_ok, negated_update=wrong_ok, half_update=half_ok)
     rep["param_rel_if_never_stepped"] = rel_l2(p0, g["final_params"])
     ref_score = torch.from_numpy(g["score"]) if "score" in g else None
@@ -214,11 +226,21 @@ def _check_against_reference(tag, loss_tol, param_tol, packed=False):
     assert rep["param_rel_final"] <= param_tol and max(rep["param_rel_steps"]) <= param_tol
     # the gates that can fail (see above) + their controls
     if "grad1_cos" in rep:
-        assert rep["grad1_cos"] >= GRAD1_COS_MIN and rep["grad1_rel"] <= GRAD1_REL_MAX, rep
+        assert rep["grad1_cos"] >= grad_gate[0] and rep["grad1_rel"] <= grad_gate[1], rep
     assert ok_update, (rep["update_cos"], rep["update_rel"])
     assert not noop_ok and not wrong_ok and not half_ok, rep["control_gate_passes"]
-    assert rep["coarse_idx_mismatch"] <= max(1, rep["n_idx"] // 20)
+    assert rep["coarse_idx_mismatch"] <= (max(1, rep["n_idx"] // 20) if max_idx_flips is None else max_idx_flips)
     assert rep["score_max_abs"] < 2e-2
+    if per_term_tol is not None:
+        assert max(rep["loss_rel"]) <= per_term_tol, rep["loss_rel"]
+    if ref_score is not None and m.get("spread", False):
+        # recall@1 far from chance on this fixture: "matching recall@1" (north_star) means something here
+        ref_top1 = ref_score.argmax(1)
+        rep["top1_agreement"] = float((r["score"].argmax(1) == ref_top1).float().mean())
+        assert rep["recall_ref_t2i"][0] > 0.5
+        assert mine["image_retrieval_recall@1"] == pytest.approx(rep["recall_ref_t2i"][0], abs=1e-7), mine
+        assert rep["top1_agreement"] == 1.0, rep["top1_agreement"]
+        _report(tag + ("_packed" if packed else ""), rep)
     return rep
 
 
@@ -232,6 +254,64 @@ def test_vitb32_b32_epoch_vs_reference():
 
 def test_vitb32_b256_epoch_vs_reference():
     _check_against_reference("vitb32_b256", loss_tol=1e-3, param_tol=1e-3)
+
+
+def test_vitb32_spread_b256_epoch_vs_reference():
+    """The NON-DEGENERATE fixture (VERDICT r2 next #1a): "spread" weights (tests/golden/make_spread_weights.py) and
+    related caption sets -- text-text cosine ~0.29, image-image ~0.50, recall@1 ~0.7 -- run through the reference's
+    unmodified train_one_epoch at ViT-B-32, B = 256.  Gated per term at SURVEY.md §8(d)'s 1e-3 (the semantics-reversion
+    term included), zero coarse-index flips, top-1 retrieval identical to the reference's on every row."""
+    _check_against_reference("vitb32_spread_b256", loss_tol=1e-3, param_tol=1e-3, per_term_tol=1e-3, max_idx_flips=0,
+                             grad_gate=SPREAD_GRAD_GATE, update_gate=SPREAD_UPDATE_GATE)
+
+
+def test_vitb32_spread_b256_packed_epoch_vs_reference():
+    _check_against_reference("vitb32_spread_b256", loss_tol=1e-3, param_tol=1e-3, packed=True, per_term_tol=1e-3,
+                             max_idx_flips=0, grad_gate=SPREAD_GRAD_GATE, update_gate=SPREAD_UPDATE_GATE)
+
+
+@pytest.mark.parametrize("tag", ["vitb32_b32", "vitb32_b256", "vitb32_spread_b256"])
+def test_sr_term_flip_vs_value_attribution(tag):
+    """Separates the two ways the semantics-reversion term (train_TTA.py:53-65, a hinge-MAX over a row of outputs_aux)
+    can differ from the reference's at step 1, where both sides hold identical parameters (VERDICT r2 next #1b):
+      free   -- the HIP path's own coarse indices (an index FLIP swaps a whole column of outputs_aux);
+      forced -- the reference's coarse_idx forced on the HIP features (same columns: what is left is the bf16 feature
+                noise inside s_ii - s_ij, divided by T2 = 0.07).
+    Reported per fixture in parity_report.json; on the spread fixture both must meet 1e-3 of the term itself, on the
+    collinear ones the forced value is bounded by 2 % of the term and by 1e-3 of the total loss."""
+    g = load_golden(tag)
+    m = g["meta"]
+    cfg = synth.get_cfg(m["model"])
+    spread = m.get("spread", False)
+    model, sd = _model(m["model"], m["wseed"], spread=spread)
+    tb, ib = make_batches(cfg, m["n_text"], m["n_image"], m["bs_text"], m["bs_image"], m["dseed"], related=spread)
+    G = torch.zeros(m["n_image"], cfg["embed_dim"], device=DEV)
+    with torch.no_grad():
+        for images, index in ib:
+            G[index.to(DEV)] = model.encode_image(images.to(DEV), normalize=True)
+    text, pos, neg, inv, _ = tb[0]
+    B = text.shape[0]
+    tower = model._text_tower()
+    feats, _ = tower.forward(torch.cat([text, pos, inv, neg], dim=0).to(DEV), True, False)
+    t, p, v, n = feats[:B], feats[B:2 * B], feats[2 * B:3 * B], feats[3 * B:]
+    coarse, idx, _ = ops.coarse_align(t, p, n, G)
+    idx_ref = torch.from_numpy(g["coarse_idx"][0][:B].astype(np.int64)).to(DEV)
+    free = ops.tta_loss_fwd_bwd(t, p, v, t, coarse, m["T1"], m["T2"], 0)[0].cpu()
+    forced = ops.tta_loss_fwd_bwd(t, p, v, t, G[idx_ref].contiguous(), m["T1"], m["T2"], 0)[0].cpu()
+    ref = torch.tensor([g["loss_ent"][0], g["loss_sr"][0], g["loss_tri"][0]], dtype=torch.float64)
+    rel = lambda x: [abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(x, ref)]
+    rep = dict(rows=B, idx_flips=int((idx.long() != idx_ref).sum()), loss_ref=[float(x) for x in ref],
+               loss_free=[float(x) for x in free], loss_forced_ref_idx=[float(x) for x in forced],
+               rel_free=rel(free), rel_forced_ref_idx=rel(forced),
+               sr_abs_over_total_free=abs(float(free[1]) - float(ref[1])) / float(ref.sum()),
+               sr_abs_over_total_forced=abs(float(forced[1]) - float(ref[1])) / float(ref.sum()))
+    _report("sr_attribution_" + tag, rep)
+    print(json.dumps(rep, indent=1))
+    if spread:
+        assert rep["idx_flips"] == 0 and max(rep["rel_free"]) <= 1e-3 and max(rep["rel_forced_ref_idx"]) <= 1e-3, rep
+    else:
+        assert rep["rel_forced_ref_idx"][1] <= 2e-2 and rep["sr_abs_over_total_forced"] <= 1e-3, rep
+        assert rep["rel_forced_ref_idx"][0] <= 2e-3 and rep["rel_forced_ref_idx"][2] <= 2e-3, rep
 
 
 def test_vitl14_b128_epoch_vs_reference():
@@ -285,18 +365,20 @@ def test_vitl14_step_at_config3_shard_vs_oracle():
     assert rep["grad_cos"] >= GRAD1_COS_MIN and rep["grad_rel"] <= GRAD1_REL_MAX, rep
 
 
-def test_gradient_error_attribution():
+@pytest.mark.parametrize("spread", [False, True])
+def test_gradient_error_attribution(spread):
     """Where does the 2-4 % error of the step-1 LayerNorm gradient (grad1_rel) come from?  ViT-B-32, 32 rows.
     (a) forward: the loss gradient w.r.t. the FEATURES, computed by the same fp32 loss kernel from HIP features and from
         the oracle's fp32 features (same coarse images) -- the share caused by bf16 noise in the forward pass;
     (b) backward: the oracle's feature gradient pushed through the HIP backward pass vs through the oracle's -- the
         share caused by bf16 operands in the data-gradient GEMMs.  Reported in parity_report.json; DESIGN.md §2."""
     name = "ViT-B-32"
-    model, sd = _model(name, 0)
+    model, sd = _model(name, 0, spread=spread)
     cfg = synth.get_cfg(name)
     t = cfg["text_cfg"]
     B = 32
-    toks = synth.synth_caption_sets(B, t["context_length"], t["vocab_size"], 1234)
+    toks = (synth.synth_related_caption_sets if spread else synth.synth_caption_sets)(
+        B, t["context_length"], t["vocab_size"], 1234)
     G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"], generator=torch.Generator().manual_seed(3)), dim=-1)
     oc.freeze_parameters(model, False)
     params, _ = oc.collect_params(model, False)
@@ -332,10 +414,11 @@ def test_gradient_error_attribution():
                grad_rel_backward_only=rel_l2(g_hip, g_ref), grad_rel_total=rel_l2(g_all, g_ref),
                grad_cos_backward_only=min_cosine(g_hip.view(1, -1), g_ref.view(1, -1)),
                grad_cos_total=min_cosine(g_all.view(1, -1), g_ref.view(1, -1)))
-    _report("gradient_error_attribution_vitb32_b32", rep)
+    _report("gradient_error_attribution_vitb32_b32" + ("_spread" if spread else ""), rep)
     print(json.dumps(rep, indent=1))
-    assert rep["grad_cos_total"] >= GRAD1_COS_MIN and rep["grad_rel_total"] <= GRAD1_REL_MAX, rep
-    assert rep["grad_rel_backward_only"] <= GRAD1_REL_MAX, rep
+    cos_min, rel_max = SPREAD_GRAD_GATE if spread else (GRAD1_COS_MIN, GRAD1_REL_MAX)
+    assert rep["grad_cos_total"] >= cos_min and rep["grad_rel_total"] <= rel_max, rep
+    assert rep["grad_rel_backward_only"] <= rel_max, rep
 
 
 def test_train_one_epoch_dropin_matches_manual_loop():
