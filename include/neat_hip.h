@@ -201,8 +201,13 @@ int neat_coarse_align(const float* q, const float* pos, const float* neg, const 
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-tile partial results live in a 2-MiB
  * file-scope device array that every GPU the library runs on holds until the process ends.  Limit:
  * B * ceil(N / 64) <= neat_coarse_static_max_slots() (= 262 144, e.g. B = 2048 with N = 8192); larger problems return
- * NEAT_ERR_SHAPE.  All calls on one GPU share that array: calls that overlap on one GPU (different streams) race. */
+ * NEAT_ERR_SHAPE.  All calls on one GPU share that array: calls that overlap on one GPU (different streams, or two host
+ * threads) race.  Set-up: the array's device address is looked up once per device (hipGetSymbolAddress, a synchronous
+ * call that may load the code object) -- by neat_coarse_static_init() with that device current, or else by the first
+ * neat_coarse_align_static call on the device.  Under HIP graph capture call neat_coarse_static_init() (or make one
+ * warm-up call) on every device BEFORE the capture begins. */
 long neat_coarse_static_max_slots(void);
+int neat_coarse_static_init(void);
 int neat_coarse_align_static(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
                              int32_t* idx_out, float* coarse_out, int B, int N, int D, void* stream);
 

@@ -580,6 +580,14 @@ static int coarse_scratch(float** out) {
 
 extern "C" long neat_coarse_static_max_slots(void) { return COARSE_STATIC_SLOTS; }
 
+// set-up of the allocation-free entry point for the CURRENT device: looks up the device address of the scratch array
+// (hipGetSymbolAddress is a synchronous lookup that may load the code object: not something to do while a stream is
+// capturing).  Idempotent; neat_coarse_align_static does the same on its first call on a device.
+extern "C" int neat_coarse_static_init(void) {
+    float* ws = nullptr;
+    return coarse_scratch(&ws);
+}
+
 extern "C" int neat_coarse_align_static(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
                                         int32_t* idx_out, float* coarse_out, int B, int N, int D, void* stream) {
     NEAT_REQUIRE(q && pos && neg && G && S_out && idx_out && coarse_out, NEAT_ERR_ARG,

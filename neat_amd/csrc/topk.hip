@@ -720,7 +720,9 @@ __global__ __launch_bounds__(256) void recall_owner_kernel(const int32_t* __rest
     int q = 0, tp = 0;
     for (int j = 0; j < K && q < nk; ++j) {
         const int c = idx[(long)r * K + j];
-        if (c >= 0) tp += ((row_owner && c == own) || (col_owner && col_owner[c] == r)) ? 1 : 0;
+        // c == 0x7fffffff: the top-k kernels' filler for a row with fewer than K selectable entries (-inf / NaN scores):
+        // no column, so never a positive -- and never an index into col_owner
+        if (c >= 0 && c != 0x7fffffff) tp += ((row_owner && c == own) || (col_owner && col_owner[c] == r)) ? 1 : 0;
         while (q < nk && ks[q] == j + 1) recall[(long)q++ * R + r] = (float)tp / n;   // 0/0 -> NaN like torch
     }
     for (; q < nk; ++q) recall[(long)q * R + r] = (float)tp / n;                     // cut-offs beyond K: all of the list

@@ -23,6 +23,43 @@ def _score_batch(model, image_tensor, captions, tokenizer, device):
     return pred.long().cpu()
 
 
+class GraphedScorer:
+    """The scorer of one batch shape as ONE HIP graph: encode_image + encode_text + normalise + einsum + arg-max are
+    ~190 small launches at BASELINE config 5's batch (64 images x 2 captions), and the host's launch path, not the GPU, sets
+    the latency.  Inputs are copied into static buffers, the graph is replayed, outputs live in static buffers (valid
+    until the next call).  Weights are read through their pointers at replay time, so LayerNorm parameters adapted IN
+    PLACE after the capture are honoured; a model whose parameter tensors are REPLACED must be captured again."""
+
+    def __init__(self, model, batch: int, num_options: int, context_length: int, image_size: int, device):
+        self.model, self.B, self.n = model, batch, num_options
+        self.img = torch.zeros(batch, 3, image_size, image_size, device=device)
+        self.tok = torch.zeros(num_options * batch, context_length, dtype=torch.int64, device=device)
+        self.tok[:, 0] = 1                                        # any valid row for the warm-up passes
+        cur = torch.cuda.current_stream(device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                             # first use of every kernel / packed weight: not captured
+            for _ in range(2):
+                self._run()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.scores, self.pred = self._run()
+
+    def _run(self):
+        with torch.no_grad():
+            fi = self.model.encode_image(self.img, normalize=True)
+            ft = self.model.encode_text(self.tok, normalize=True).view(self.n, self.B, -1)
+            return ops.mcq_scores(fi, ft)
+
+    def __call__(self, images, tokens):
+        self.img.copy_(images, non_blocking=True)
+        self.tok.copy_(tokens, non_blocking=True)
+        self.graph.replay()
+        return self.scores, self.pred
+
+
 TYPES = ("positive", "negative", "hybrid")
 
 
@@ -86,9 +123,24 @@ def evaluate_binary_mcq_model(model, dataloader, args, tokenizer):
     return {"total_accuracy": correct / len(dataloader.dataset)}
 
 
+CXR_DATASETS = ("chexpert-binary-mcq", "chexpert-affirmation-binary-mcq")
+
+
 def mcq_eval(model, data, epoch, args, tokenizer=None):
-    """mcq.py:296-389: result keys per dataset present in ``data`` (the HF-PLIP CheXpert branch is out of scope)."""
+    """mcq.py:296-389: result keys per dataset present in ``data``.
+
+    ``args.cxr_dataset`` (mcq.py:330-339, BASELINE config 5): the two CheXpert binary sets, one ``-total_accuracy`` key
+    each.  The reference scores them with a HuggingFace PLIP model (``evaluate_binary_mcq_model_hf`` :220-294: per image
+    ``einsum('bd,bnd->bn')`` over its two captions + arg-max); with an open_clip-layout model -- what this package
+    adapts, and what ``replace_text_layernorm_params`` hands over to PLIP -- the same scoring is
+    ``evaluate_binary_mcq_model`` (:149-217), which is what runs here."""
     results = {}
+    if getattr(args, "cxr_dataset", False) and not getattr(args, "video", False):
+        for name in CXR_DATASETS:
+            if name in data:
+                m = evaluate_binary_mcq_model(model, data[name].dataloader, args, tokenizer)
+                results[f"{name}-total_accuracy"] = m["total_accuracy"]
+        return results
     names = ["msrvtt-mcq"] if getattr(args, "video", False) else ["synthetic-mcq", "coco-mcq", "voc2007-mcq"]
     for name in names:
         if name not in data:

@@ -39,14 +39,25 @@ def get_model_config(model_name):
     return deepcopy(_MODEL_CONFIGS.get(model_name.replace("/", "-")))
 
 
-def load_checkpoint(model, checkpoint_path, strict=True):
+OPENAI_FORMAT_KEYS = ("input_resolution", "context_length", "vocab_size")
+
+
+def _read_state_dict(checkpoint_path):
+    """-> (state dict, is_openai_format).  An OpenAI-format state dict carries three scalar entries beside the weights
+    (reference open_clip/model.py:450-506 strips them); those checkpoints were trained with QuickGELU (:498)."""
     sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     if next(iter(sd)).startswith("module"):
         sd = {k[7:]: v for k, v in sd.items()}
-    for k in ("input_resolution", "context_length", "vocab_size"):
+    openai = all(k in sd for k in OPENAI_FORMAT_KEYS)
+    for k in OPENAI_FORMAT_KEYS:
         sd.pop(k, None)
+    return sd, openai
+
+
+def load_checkpoint(model, checkpoint_path, strict=True, state_dict=None):
+    sd = state_dict if state_dict is not None else _read_state_dict(checkpoint_path)[0]
     return model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=strict)
 
 
@@ -54,7 +65,13 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
                  device: Union[str, torch.device] = "cpu", force_quick_gelu: bool = False, **model_kwargs):
     """reference factory.py:166-321.  ``pretrained`` may be a local checkpoint path; named tags need the
     network and are unavailable offline.  ``precision`` is accepted for CLI compatibility: master weights
-    stay fp32 and the kernels compute bf16 x bf16 -> fp32 regardless."""
+    stay fp32 and the kernels compute bf16 x bf16 -> fp32 regardless.
+
+    Activation: the kernels implement QuickGELU.  A checkpoint is accepted when the config says ``quick_gelu``, when the
+    caller passes ``force_quick_gelu=True``, or when the file is an OpenAI-format state dict (it carries
+    ``input_resolution / context_length / vocab_size``; the reference enables QuickGELU itself for those,
+    open_clip/model.py:498) -- any other checkpoint raises, because an nn.GELU checkpoint has the same keys and would
+    load cleanly and give wrong features."""
     cfg = get_model_config(model_name)
     if cfg is None:
         raise RuntimeError(f"Model config for {model_name} not found; available: {list_models()}")
@@ -64,14 +81,18 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     # the activation must be the one the weights were trained with: an nn.GELU checkpoint (e.g. laion ViT-B-32) has the
     # same state-dict keys and would load cleanly and give wrong features, so the caller has to say QuickGELU.
     quick_gelu = bool(cfg.get("quick_gelu", False) or force_quick_gelu)
+    state_dict = None
+    if pretrained and os.path.exists(pretrained):
+        state_dict, openai_format = _read_state_dict(pretrained)
+        quick_gelu = quick_gelu or openai_format
     if pretrained and not quick_gelu:
         raise RuntimeError(f"create_model({model_name!r}, pretrained={pretrained!r}): only QuickGELU (OpenAI-family) "
                            f"weights are supported; pass force_quick_gelu=True (or a *-quickgelu config) if the "
                            f"checkpoint was trained with QuickGELU")
     model = CLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)
     if pretrained:
-        if os.path.exists(pretrained):
-            load_checkpoint(model, pretrained)
+        if state_dict is not None:
+            load_checkpoint(model, pretrained, state_dict=state_dict)
         else:
             raise RuntimeError(f"Pretrained weights ({pretrained}) not found locally; named tags need network access")
     if "pack_tokens" in model_kwargs:

@@ -736,6 +736,52 @@ def test_offline_eval_and_mcq_match_oracle():
         assert len(lines) == 1 and set(_json.loads(lines[0])) == set(res)
 
 
+def test_config5_at_model_size_vitb16_binary_mcq_vs_oracle():
+    """BASELINE config 5 at MODEL size (VERDICT r2 next #1d): ViT-B-16, one batch of 64 images x 2 captions through
+    ``mcq_eval``'s CheXpert branch (reference evaluation/mcq.py:199-205, 330-339) against the fp32 oracle on the host:
+    per-image logits within 2e-2, the prediction identical wherever the oracle's margin is clear of that bound, the two
+    result keys, and the graph-replayed scorer equal to the eager one."""
+    from neat_amd.evaluation import mcq as MQ
+    name = "ViT-B-16"
+    model, sd = _model(name, 0)
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    tok = _fake_tokenizer(t["context_length"], t["vocab_size"])
+    gen = torch.Generator().manual_seed(17)
+    B = 64
+    imgs = synth.synth_images(B, 224, 31)
+    caps = [[" ".join(str(int(x)) for x in torch.randint(0, 40000, (int(torch.randint(4, 12, (1,), generator=gen)),),
+                                                         generator=gen)) for _ in range(B)] for _ in range(2)]
+    answers = torch.randint(0, 2, (B,), generator=gen)
+    fi = O.encode_image_fwd(sd, imgs)
+    ft = torch.stack([O.encode_text_fwd(sd, tok(c))[0] for c in caps])
+    logits = torch.einsum("bf,nbf->bn", fi, ft)
+    # kernel-level: scores and predictions of the batch
+    with torch.no_grad():
+        gi = model.encode_image(imgs.to(DEV), normalize=True)
+        gt = model.encode_text(torch.cat([tok(c) for c in caps]).to(DEV), normalize=True).view(2, B, -1)
+    scores, pred = ops.mcq_scores(gi, gt)
+    assert min_cosine(gi.cpu(), fi) >= 0.999 and min_cosine(gt.cpu().view(2 * B, -1), ft.view(2 * B, -1)) >= 0.999
+    assert (scores.cpu() - logits).abs().max().item() < 2e-2
+    clear = (logits[:, 0] - logits[:, 1]).abs() > 2e-2
+    assert torch.equal(pred.cpu().long()[clear], logits.argmax(1)[clear])
+    # through the caller: the cxr branch of mcq_eval, both CheXpert sets
+    args = types.SimpleNamespace(device=DEV, batch_size=B, video=False, cxr_dataset=True)
+    data = {k: types.SimpleNamespace(dataloader=_ListLoader([(imgs, caps, answers)], B)) for k in MQ.CXR_DATASETS}
+    res = MQ.mcq_eval(model, data, 0, args, tok)
+    assert set(res) == {"chexpert-binary-mcq-total_accuracy", "chexpert-affirmation-binary-mcq-total_accuracy"}
+    ref_acc = float((logits.argmax(1) == answers).float().mean())
+    for v in res.values():
+        assert abs(v - ref_acc) <= float((~clear).sum()) / B + 1e-6
+    _report("config5_vitb16_mcq", dict(score_max_abs=float((scores.cpu() - logits).abs().max()),
+                                       unclear_margins=int((~clear).sum()), accuracy=res, accuracy_oracle=ref_acc))
+    # one HIP graph per batch shape replays the same scorer (bench.py --workload mcq measures both)
+    gs = MQ.GraphedScorer(model, B, 2, t["context_length"], 224, torch.device(DEV))
+    s2, p2 = gs(imgs.to(DEV), torch.cat([tok(c) for c in caps]).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(p2, pred) and torch.equal(s2, scores)
+
+
 def test_video_pooling_matches_oracle():
     model, sd = _model("neat-tiny", 0)
     clips = synth.synth_images(3 * 4, 32, 5).view(3, 4, 3, 32, 32)

@@ -133,3 +133,40 @@ def test_video_csv_to_scores_flow(tmp_path):
            toy_tokenizer(text_ds.inv_text), torch.arange(5))]
     ref = run(Fake(tb, 5, "text"), Fake(vb, 5, "image"), lambda x: x)
     assert torch.equal(t2i, ref)
+
+
+def test_config4_at_model_size_vitb32_clips_vs_oracle():
+    """BASELINE config 4 at MODEL size (VERDICT r2 next #1d): ViT-B-32 ``encode_video`` over [8, 4, 3, 224, 224] clips --
+    32 frames folded into the batch, per-frame L2-norm, mean over the 4 frames, re-normalise (reference
+    utils/video_utils/model.py:41-91) -- against the fp32 oracle on the host, then one ViT-B-32 TTA step whose gallery
+    is those pooled clip embeddings (8 caption rows) against the oracle's step."""
+    from neat_amd import open_clip as oc, synth, train_TTA as T
+    from neat_amd.optim import AdamW
+    from oracle import neat_oracle as O
+
+    name = "ViT-B-32"
+    cfg = synth.get_cfg(name)
+    sd = synth.synth_state_dict(name, 0)
+    model = oc.VideoCLIP(oc.create_model(name, device=DEV))
+    model.clip.load_state_dict(sd, strict=True)
+    clips = synth.synth_images(8 * 4, 224, 77).view(8, 4, 3, 224, 224)
+    with torch.no_grad():
+        got = model.encode_video(clips.to(DEV)).cpu()
+        alias = model.encode_image(clips.to(DEV), normalize=True).cpu()
+    want = O.encode_video_fwd(sd, clips)
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1).min().item()
+    assert cos >= 0.999, cos
+    assert torch.equal(alias, got)                                  # encode_image is the alias the TTA loop calls (:76-91)
+    assert (got.norm(dim=-1) - 1).abs().max().item() < 1e-5
+    # one adaptation step against this gallery
+    t = cfg["text_cfg"]
+    toks = synth.synth_caption_sets(8, t["context_length"], t["vocab_size"], 99)
+    oc.freeze_parameters(model, False)
+    opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+    losses, idx, S = T.tta_step(model.clip, opt, [x.to(DEV) for x in toks], got.to(DEV), 0.03, 0.07)
+    st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
+    l_ref, idx_ref, S_ref, _, _ = O.tta_step(sd, st, toks, want, 2e-4, 1e-3, 0.03, 0.07)
+    tot = float(l_ref.sum())
+    assert abs(float(losses.sum().cpu()) - tot) <= 1e-3 * abs(tot), (losses.tolist(), l_ref.tolist())
+    assert (S.cpu() - S_ref).abs().max().item() < 2e-2
+    assert int((idx.cpu().long() != idx_ref).sum()) <= 1

@@ -155,6 +155,38 @@ def test_mcq_wrong_pick_of_option_zero_outside_synthetic_sets_raises(monkeypatch
         MQ.evaluate_model(M(), L(), types.SimpleNamespace(device="cpu"), None, is_synthetic=False)
 
 
+def test_mcq_eval_cxr_branch_reports_the_two_chexpert_keys(monkeypatch):
+    """args.cxr_dataset (reference mcq.py:330-339, BASELINE config 5): binary scorer, two result keys, nothing else."""
+    preds = {"chexpert-binary-mcq": [torch.tensor([0, 1, 1, 0]), torch.tensor([1, 1])],
+             "chexpert-affirmation-binary-mcq": [torch.tensor([1, 1, 1, 1]), torch.tensor([0, 0])]}
+    answers = [torch.tensor([0, 1, 0, 0]), torch.tensor([1, 0])]                 # 4 / 6 and 2 / 6 right
+    cursor = {}
+    monkeypatch.setattr(MQ, "_score_batch", lambda model, image, captions, tok, dev: next(cursor[image]))
+
+    class L:
+        dataset = list(range(6))
+
+        def __init__(self, name):
+            self.name = name
+
+        def __iter__(self):
+            cursor[self.name] = iter(preds[self.name])
+            caps = [["no evidence of edema"] * 4, ["edema is present"] * 4]
+            return iter([(self.name, caps, answers[0]), (self.name, [c[:2] for c in caps], answers[1])])
+
+    class M:
+        def eval(self):
+            pass
+
+    data = {n: types.SimpleNamespace(dataloader=L(n)) for n in preds}
+    data["coco-mcq"] = None                                                       # ignored on this branch
+    out = MQ.mcq_eval(M(), data, 0, types.SimpleNamespace(device="cpu", cxr_dataset=True, video=False), None)
+    assert out == {"chexpert-binary-mcq-total_accuracy": 4 / 6, "chexpert-affirmation-binary-mcq-total_accuracy": 2 / 6}
+    only = MQ.mcq_eval(M(), {"chexpert-binary-mcq": data["chexpert-binary-mcq"]}, 0,
+                       types.SimpleNamespace(device="cpu", cxr_dataset=True, video=False), None)
+    assert list(only) == ["chexpert-binary-mcq-total_accuracy"]
+
+
 # ------------------------------------------------------------------ factory
 def test_pretrained_checkpoint_needs_an_explicit_quick_gelu(tmp_path):
     sd = synth.synth_state_dict("neat-tiny", 0)
@@ -164,6 +196,13 @@ def test_pretrained_checkpoint_needs_an_explicit_quick_gelu(tmp_path):
         oc.create_model("neat-tiny", pretrained=str(ck), device="cpu")
     m = oc.create_model("neat-tiny", pretrained=str(ck), device="cpu", force_quick_gelu=True)
     assert torch.equal(m.text_projection.detach(), sd["text_projection"])
+    # an OpenAI-format state dict (the three scalar entries beside the weights) says QuickGELU by itself, as in the
+    # reference (open_clip/model.py:450-506): create_model_and_transforms(name, pretrained=<OpenAI .pt>) works unchanged
+    sd_openai = dict(sd, input_resolution=torch.tensor(32), context_length=torch.tensor(16), vocab_size=torch.tensor(512))
+    ck2 = tmp_path / "openai.pt"
+    torch.save(sd_openai, ck2)
+    m2, _, _ = oc.create_model_and_transforms("neat-tiny", pretrained=str(ck2), device="cpu")
+    assert torch.equal(m2.text_projection.detach(), sd["text_projection"])
 
 
 # ------------------------------------------------------------------ bench.py starts its own ranks
