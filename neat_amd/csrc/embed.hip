@@ -46,24 +46,25 @@ __global__ __launch_bounds__(256) void eot_index_kernel(const int64_t* __restric
 // With a causal mask and EOT pooling (open_clip/transformer.py:555-558, 655-661) no position after the EOT token
 // can influence the pooled feature or receive a gradient from it, so those rows are dead work.  The packed
 // layout keeps rows 0..eot of every sequence back to back: cu[s] = first row of sequence s, cu[nseq] = rows.
-__global__ __launch_bounds__(256) void pack_plan_kernel(const int64_t* __restrict__ tokens, int32_t* __restrict__ eot,
-                                                        int32_t* __restrict__ cu, int nseq, int L) {
-    extern __shared__ int32_t len_s[];
-    for (int s = threadIdx.x; s < nseq; s += blockDim.x) {
-        const int64_t* t = tokens + (long)s * L;
-        int64_t best = t[0];
-        int bi = 0;
-        for (int l = 1; l < L; ++l)
-            if (t[l] > best) { best = t[l]; bi = l; }
-        eot[s] = bi;
-        len_s[s] = bi + 1;
-    }
+// cu = exclusive prefix sum of (eot + 1), one block: every thread sums a contiguous run of sequences, the 256 run totals
+// are scanned in LDS, every thread then writes its run.  (The EOT positions come from eot_index_kernel, one wavefront
+// per sequence with coalesced loads: one thread walking a 77-token row per sequence took 96 us for 1 024 captions.)
+__global__ __launch_bounds__(256) void pack_scan_kernel(const int32_t* __restrict__ eot, int32_t* __restrict__ cu, int nseq) {
+    __shared__ int32_t tot[256];
+    const int per = (nseq + 255) / 256;
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, nseq);
+    int acc = 0;
+    for (int s = s0; s < s1; ++s) acc += eot[s] + 1;
+    tot[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int s = 0; s < nseq; ++s) { cu[s] = acc; acc += len_s[s]; }
-        cu[nseq] = acc;
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = tot[i]; tot[i] = run; run += v; }
+        cu[nseq] = run;
     }
+    __syncthreads();
+    acc = tot[threadIdx.x];
+    for (int s = s0; s < s1; ++s) { cu[s] = acc; acc += eot[s] + 1; }
 }
 
 // one block per sequence: rows cu[s] .. cu[s+1]-1 <- token embedding + positional embedding
@@ -310,8 +311,8 @@ extern "C" int neat_eot_index(const int64_t* tokens, int32_t* eot, int nseq, int
 extern "C" int neat_pack_plan(const int64_t* tokens, int32_t* eot, int32_t* cu_seqlens, int nseq, int L, void* stream) {
     NEAT_REQUIRE(tokens && eot && cu_seqlens, NEAT_ERR_ARG, "neat_pack_plan: null pointer");
     NEAT_REQUIRE(nseq > 0 && nseq <= 12000 && L > 0, NEAT_ERR_SHAPE, "neat_pack_plan: nseq=%d L=%d (nseq <= 12000)", nseq, L);
-    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), (size_t)nseq * 4, (hipStream_t)stream, tokens, eot,
-                       cu_seqlens, nseq, L);
+    hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream, tokens, eot, nseq, L);
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, eot, cu_seqlens, nseq);
     NEAT_LAUNCH_CHECK("neat_pack_plan");
     return NEAT_OK;
 }

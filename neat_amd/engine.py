@@ -114,9 +114,17 @@ class TextTower:
         self.proj = model.text_projection.detach().contiguous()
         self.proj_t = self.proj.t().contiguous()          # frozen: transposed once for the forward tile GEMM
 
-    def forward(self, tokens, normalize: bool, save: bool, packed: bool = False, n_grad=None):
+    def plan(self, tokens):
+        """The packed layout of a token batch: (tokens, cu int32 [nseq+1] on the device, cu on the host).  It depends on
+        the tokens only, so a caller that encodes the same batch several times (the tta_steps of one adaptation batch)
+        computes it -- and pays its device-to-host copy -- once and passes it to ``forward(..., plan=)``."""
+        tokens = tokens.contiguous()
+        _, cu = ops.pack_plan(tokens)
+        return tokens, cu, cu.cpu()
+
+    def forward(self, tokens, normalize: bool, save: bool, packed: bool = False, n_grad=None, plan=None):
         """tokens int64 [nseq, L] -> (feat fp32 [nseq, D], ctx).  n_grad: only the first n_grad sequences will be
-        passed to ``backward`` (default: all).
+        passed to ``backward`` (default: all).  plan: ``self.plan(tokens)`` of these very tokens (packed runs).
 
         ``packed``: run only positions 0..EOT of every sequence (rows back to back).  With the causal mask and
         EOT pooling the positions after EOT cannot reach the pooled feature, nor receive gradient from it, so
@@ -125,8 +133,13 @@ class TextTower:
         nseq, L = tokens.shape
         saved = [] if save else None
         if packed:
-            eot, cu = ops.pack_plan(tokens)
-            cu_host = cu.cpu()                                    # one small D2H copy: row counts size the buffers
+            if plan is not None:
+                tokens, cu, cu_host = plan
+                if tuple(tokens.shape) != (nseq, L):
+                    raise RuntimeError("TextTower.forward: the plan belongs to another token batch")
+            else:
+                _, cu = ops.pack_plan(tokens)
+                cu_host = cu.cpu()                                # one small D2H copy: row counts size the buffers
             rows, Lmax = int(cu_host[-1]), int((cu_host[1:] - cu_host[:-1]).max())
             x = ops.embed_packed_fwd(tokens, cu, rows, self.tok, self.pos)
             x = self.stack.forward(x, nseq, Lmax, saved, cu=cu,

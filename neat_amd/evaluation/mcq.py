@@ -48,10 +48,16 @@ class GraphedScorer:
             self.scores, self.pred = self._run()
 
     def _run(self):
-        with torch.no_grad():
-            fi = self.model.encode_image(self.img, normalize=True)
-            ft = self.model.encode_text(self.tok, normalize=True).view(self.n, self.B, -1)
-            return ops.mcq_scores(fi, ft)
+        clip = self.model.clip if hasattr(self.model, "clip") else self.model
+        packed = getattr(clip, "pack_tokens", False)
+        clip.pack_tokens = False              # packed text batches size their buffers from a device-to-host copy: not capturable
+        try:
+            with torch.no_grad():
+                fi = self.model.encode_image(self.img, normalize=True)
+                ft = self.model.encode_text(self.tok, normalize=True).view(self.n, self.B, -1)
+                return ops.mcq_scores(fi, ft)
+        finally:
+            clip.pack_tokens = packed
 
     def __call__(self, images, tokens):
         self.img.copy_(images, non_blocking=True)

@@ -138,8 +138,12 @@ class CLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
         self.logit_bias = None
         self._towers = {}
-        # opt-in: encode only positions 0..EOT of each caption (engine.TextTower.forward, packed=True)
-        self.pack_tokens = os.environ.get("NEAT_PACK_TOKENS", "0") not in ("", "0")
+        # default ON: the text tower runs only positions 0..EOT of each caption (engine.TextTower.forward, packed=True):
+        # behind the causal mask (reference transformer.py:655-661) and EOT pooling (:555-558) the later positions can
+        # neither reach the pooled feature nor receive gradient from it -- same features, losses and LN gradients up to
+        # fp32 summation order.  NEAT_PACK_TOKENS=0 (or model.pack_tokens = False) runs all context_length positions
+        # like the reference does.
+        self.pack_tokens = os.environ.get("NEAT_PACK_TOKENS", "1") not in ("", "0")
         self.init_parameters()
 
     # -- init: same distributions as the reference's text tower (open_clip/transformer.py:628-649) --

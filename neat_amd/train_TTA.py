@@ -10,8 +10,9 @@ What differs from the reference, by design:
   * loss, gradient and the coarse alignment are fused fp32 kernels; AdamW is one launch when the optimizer
     is ``neat_amd.optim.AdamW`` (any torch optimizer over the same parameters also works);
   * the gallery buffer is sized from the model's embed dim (the reference hard-codes 512, :119);
-  * opt-in ``model.pack_tokens = True``: the text tower runs only positions 0..EOT of every caption (dead rows
-    behind the causal mask are dropped; same features, losses and LN gradients up to fp32 summation order);
+  * ``model.pack_tokens`` (default True; ``NEAT_PACK_TOKENS=0`` or ``model.pack_tokens = False`` turns it off): the
+    text tower runs only positions 0..EOT of every caption (dead rows behind the causal mask are dropped; same
+    features, losses and LN gradients up to fp32 summation order);
   * data parallelism: a rank owns a contiguous row shard of every caption batch and a share of the
     gallery; it all-gathers text features + coarse image features, sums the LN gradients of all ranks, and gathers the
     gallery embeddings and the score rows.  Both loader wirings are accepted, per loader: ``DistributedSampler``s as the
@@ -161,7 +162,18 @@ def _ln_grad_views(model):
     return grads
 
 
-def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global_rows=None):
+def batch_plan(model, tokens4):
+    """What the tta_steps of ONE adaptation batch share: the four token sets as one [4*Bl, L] batch ordered
+    [text, pos, inv, neg] and, with packed text batches, its packed layout (one small device-to-host copy).  Pass the
+    result to every ``tta_step(..., plan=)`` of the batch."""
+    text, pos, neg, inv = tokens4
+    toks = torch.cat([text, pos, inv, neg], dim=0)
+    if bool(getattr(model, "pack_tokens", False)) and toks.is_cuda:
+        return model._text_tower().plan(toks)
+    return (toks, None, None)
+
+
+def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global_rows=None, plan=None):
     """One inner step (train_TTA.py:133-147) on this rank's row shard.  tokens4 = (text,pos,neg,inv) int64
     [Bl, L] on the GPU.  Returns (losses[3] tensor, coarse idx, sims_matrix) for the local rows.
     global_rows: rows of the global batch when the caller knows them (shards cut by ``_shard``); without it the
@@ -169,8 +181,10 @@ def tta_step(model, optimizer, tokens4, gallery, T1, T2, world=1, rank=0, global
     text, pos, neg, inv = tokens4
     Bl = text.shape[0]
     tower = model._text_tower()
-    feats, ctx = tower.forward(torch.cat([text, pos, inv, neg], dim=0), True, True,
-                               packed=bool(getattr(model, "pack_tokens", False)), n_grad=3 * Bl)     # neg: no backward
+    packed = bool(getattr(model, "pack_tokens", False))
+    toks = plan[0] if plan is not None else torch.cat([text, pos, inv, neg], dim=0)
+    kw = dict(plan=plan) if (packed and plan is not None and plan[1] is not None) else {}
+    feats, ctx = tower.forward(toks, True, True, packed=packed, n_grad=3 * Bl, **kw)                 # neg: no backward
     t, p, v, n = feats[:Bl], feats[Bl:2 * Bl], feats[2 * Bl:3 * Bl], feats[3 * Bl:]
     coarse, idx, S = ops.coarse_align(t, p, n, gallery)
     if world > 1 or FORCE_COLLECTIVES:
@@ -321,8 +335,10 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
                 raise RuntimeError(f"train_one_epoch: a batch of {Bt} caption rows cannot be cut over {world} ranks")
             lo, hi = _shard(Bt, world, rank)
             local = [x[lo:hi].contiguous() for x in toks]
+        plan = batch_plan(clip, local)
         for _ in range(args.tta_steps):
-            losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt)
+            losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt,
+                                       plan=plan)
         if world > 1:
             sims = _all_gather_rows(sims, Bt, world)
         score_matrix_t2i[idx] = sims

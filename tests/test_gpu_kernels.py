@@ -167,7 +167,11 @@ def test_gemm_exact_small_integers():
 @pytest.mark.parametrize("M,N,K,kern", [(128 * 300 + 37, 528, 512, "panel"), (128 * 260, 256, 768, "panel"),
                                         (128 * 257 + 1, 512, 1536, "panel"), (78848, 2048, 512, "panel"),
                                         (128 * 260, 256, 768, "t256"), (128 * 257 + 1, 512, 1536, "t256"),
-                                        (78848, 2048, 512, "t256"), (59136 + 77, 512, 2048, "t256")])
+                                        (78848, 2048, 512, "t256"), (59136 + 77, 512, 2048, "t256"),
+                                        # underfilled grids -> the 128 x 128 units of the panel kernel (packed text
+                                        # batches, a 250-image gallery batch): ragged rows, K = 512 / 2048 / 768
+                                        (11136 + 5, 512, 2048, "panel"), (14848, 512, 512, "panel"),
+                                        (12500, 768, 768, "panel"), (2000, 1536, 512, "panel")])
 def test_gemm_exact_at_full_size(M, N, K, kern):
     """Full-size launches (many units per workgroup, ragged rows, idle waves at N = 528, the c_fc shape) on
     small-integer operands: every bf16 output is exact, so a late or missing LDS piece cannot hide."""

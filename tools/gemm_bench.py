@@ -6,7 +6,10 @@ from neat_amd import lib, ops
 
 dev = "cuda"
 B = int(os.environ.get("B", 256))
-M4, M3 = 4 * B * 77, 3 * B * 77
+# M4 / M3: rows of the forward (4 caption sets) and backward (3) GEMMs; override for other regimes, e.g. the packed text
+# batches (M4=14848 M3=11136: 14.5 tokens per caption) or a 250-image ViT-B/32 gallery batch (M4=12500 C=768)
+M4 = int(os.environ.get("M4", 4 * B * 77))
+M3 = int(os.environ.get("M3", M4 * 3 // 4))
 C = int(os.environ.get("C", 512))                 # text width: 512 = ViT-B-32 / B-16, 768 = ViT-L-14
 shapes = [("qkv  fwd BIAS_BF16", lib.EPI_BIAS_BF16, M4, 3 * C, C), ("out  fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, C, C),
           ("fc   fwd BIAS_GELU", lib.EPI_BIAS_GELU, M4, 4 * C, C), ("proj fwd BIAS_RES", lib.EPI_BIAS_RES_F32, M4, C, 4 * C),
