@@ -173,20 +173,30 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     G_local = torch.empty(hi - lo, cfg["embed_dim"], device=dev)
     isz = cfg["vision_cfg"]["image_size"]
-    if not a.skip_gallery_encode:      # one untimed batch: module load, workspaces and the vision tower's packed weights
-        with torch.no_grad():
-            model.encode_image(torch.randn(250, 3, isz, isz, generator=g, device=dev), normalize=True)
+    # Phase A as train_one_epoch runs it: loader batches of 256 images (the reference's tta_total_bs, main_TTA.py:256)
+    # through train_TTA.GalleryEncoder, which groups them into ~50 000 token rows per encode
+    gb = 256
+    if not a.skip_gallery_encode:      # one untimed group: module load, workspaces and the vision tower's packed weights
+        enc = T.GalleryEncoder(model, dev)
+        for _ in range(4):
+            enc.add(torch.randn(gb, 3, isz, isz, generator=g, device=dev), torch.arange(gb))
+        enc.flush()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with torch.no_grad():
         if a.skip_gallery_encode:
             G_local = torch.nn.functional.normalize(torch.randn(hi - lo, cfg["embed_dim"], generator=g, device=dev), dim=-1)
         else:
-            for s in range(0, hi - lo, 250):
-                e = min(hi - lo, s + 250)
+            enc = T.GalleryEncoder(model, dev)
+            ready = []
+            for s in range(0, hi - lo, gb):
+                e = min(hi - lo, s + gb)
                 img = torch.randn(e - s, 3, isz, isz, generator=g, device=dev)
-                G_local[s:e] = model.encode_image(img, normalize=True)
-            del img
+                ready += enc.add(img, torch.arange(s, e))
+            ready += enc.flush()
+            for index, emb in ready:
+                G_local[index] = emb
+            del img, ready
     torch.cuda.synchronize()
     gallery_s = time.perf_counter() - t0
     G = T._all_gather_rows(G_local, n_img, world) if (world > 1 or force) else G_local
@@ -481,16 +491,24 @@ def gallery_workload(a):
     model.load_state_dict(synth.synth_state_dict(a.model, 0))
     isz = cfg["vision_cfg"]["image_size"]
     g = torch.Generator(device=dev).manual_seed(1234)
-    bs = 250
+    from neat_amd import train_TTA as T
+    bs = 256                                   # the reference's loader batch (tta_total_bs); grouped by GalleryEncoder
     img = torch.randn(bs, 3, isz, isz, generator=g, device=dev)
+    idx = torch.arange(bs)
     with torch.no_grad():
-        model.encode_image(img, normalize=True)
+        enc = T.GalleryEncoder(model, dev)
+        for _ in range(4):
+            enc.add(img, idx)
+        enc.flush()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
+        enc = T.GalleryEncoder(model, dev)
         while n < a.gallery:
-            model.encode_image(img[: min(bs, a.gallery - n)], normalize=True)
-            n += min(bs, a.gallery - n)
+            k = min(bs, a.gallery - n)
+            enc.add(img[:k], idx[:k])
+            n += k
+        enc.flush()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fl = vision_flops_per_image(cfg)
@@ -498,7 +516,7 @@ def gallery_workload(a):
                n_gpus=1, steps=1, warmup=1, ms_per_step=round(dt * 1e3, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="bf16", data="synthetic",
                config=dict(workload=f"Phase A of BASELINE config 2/3: {a.model} encode_image over {a.gallery} images, "
-                                    f"batches of {bs}"),
+                                    f"loader batches of {bs} grouped to ~50 000 token rows per encode"),
                roofline=dict(bound="mfma", kernel="vision tower forward (all kernels)",
                              achieved=round(a.gallery * fl / dt / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=round(a.gallery * fl / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,

@@ -185,8 +185,45 @@ __global__ __launch_bounds__(PP_THREADS) void pool_ln_bwd_kernel(const float* __
 
 // ---- ViT stem ----
 // images f32 NCHW -> bf16 patch matrix [n*gh*gw, Kpad], column order (c, kh, kw) = conv1.weight.view(width,-1)
-__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n, int H, int W, int patch,
-                                int Kpad) {
+// One workgroup per patch row (image b, patch ph, pw); a thread moves V consecutive kw of one (c, kh) line: a V x 4-byte
+// load from the image and a V x 2-byte store (V = 4 when patch % 4 == 0 -- ViT-B/32, B/16 --, else 2 -- ViT-L/14: patch 14).
+// (One element per thread with 64-bit div / mod per element ran at 0.9 TB/s: 172 us for 250 images.)
+template <int V>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int H, int W,
+                                                       int patch, int Kpad) {
+    const int gh = H / patch, gw = W / patch;
+    const int K = 3 * patch * patch;
+    const long prow = blockIdx.x;
+    const int pw = (int)(prow % gw), ph = (int)((prow / gw) % gh);
+    const long b = prow / ((long)gw * gh);
+    const float* src = img + (b * 3 * H + (long)ph * patch) * W + pw * patch;
+    bf16_t* dst = out + prow * Kpad;
+    const int pv = patch / V;                                      // vectors per (c, kh) line
+    for (int v = threadIdx.x; v < Kpad / V; v += 256) {
+        const int k = v * V;
+        float x[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[j] = 0.f;
+        if (k < K) {
+            const int line = v / pv, kw = (v - line * pv) * V;     // line = c * patch + kh
+            const int c = line / patch, kh = line - c * patch;
+            const float* p = src + ((long)c * H + kh) * W + kw;
+            if constexpr (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+            } else {
+                const float2 t = *reinterpret_cast<const float2*>(p);
+                x[0] = t.x; x[1] = t.y;
+            }
+        }
+        if constexpr (V == 4) *reinterpret_cast<uint2*>(dst + k) = make_uint2(pack2bf(x[0], x[1]), pack2bf(x[2], x[3]));
+        else *reinterpret_cast<uint32_t*>(dst + k) = pack2bf(x[0], x[1]);
+    }
+}
+
+// any other geometry (odd patch sizes, unaligned rows): one element per thread
+__global__ void patchify_scalar_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n, int H, int W, int patch,
+                                       int Kpad) {
     const int gh = H / patch, gw = W / patch;
     const int K = 3 * patch * patch;
     const long total = (long)n * gh * gw * Kpad;
@@ -379,8 +416,17 @@ extern "C" int neat_patchify(const float* images, uint16_t* patches, int n, int 
     NEAT_REQUIRE(n > 0 && patch > 0 && H % patch == 0 && W % patch == 0 && Kpad >= 3 * patch * patch, NEAT_ERR_SHAPE,
                  "neat_patchify: bad shape");
     const long total = (long)n * (H / patch) * (W / patch) * Kpad;
-    hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, images, patches, n,
-                       H, W, patch, Kpad);
+    const long prows = (long)n * (H / patch) * (W / patch);
+    const bool aligned = (uintptr_t)images % 16 == 0 && (uintptr_t)patches % 8 == 0 && prows < (1L << 31);
+    if (aligned && patch % 4 == 0 && W % 4 == 0 && Kpad % 4 == 0)
+        hipLaunchKernelGGL(patchify_kernel<4>, dim3((unsigned)prows), dim3(256), 0, (hipStream_t)stream, images, patches, H, W,
+                           patch, Kpad);
+    else if (aligned && patch % 2 == 0 && W % 2 == 0 && Kpad % 2 == 0)
+        hipLaunchKernelGGL(patchify_kernel<2>, dim3((unsigned)prows), dim3(256), 0, (hipStream_t)stream, images, patches, H, W,
+                           patch, Kpad);
+    else
+        hipLaunchKernelGGL(patchify_scalar_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, images,
+                           patches, n, H, W, patch, Kpad);
     NEAT_LAUNCH_CHECK("neat_patchify");
     return NEAT_OK;
 }

@@ -149,6 +149,42 @@ def _loader_is_sharded(loader, world: int, rank: int, what: str) -> bool:
     return smp.num_replicas > 1
 
 
+class GalleryEncoder:
+    """Phase A (train_TTA.py:120-124) with the loader's batches GROUPED before they are encoded.  The reference encodes
+    one loader batch at a time (tta_total_bs = 256 images, main_TTA.py:256); images are independent, and at ViT-B/32
+    a 256-image batch is 12 800 token rows -- less than one round of GEMM units on this chip (a layer's four GEMMs take
+    1.36 us per image at 250 images and 0.89 us at 1 000, tools/gemm_bench.py).  Batches are therefore collected until
+    ``target_rows`` token rows are at hand (or the loader ends) and encoded together; per image the result is what
+    ``model.encode_image(batch, normalize=True)`` gives."""
+
+    def __init__(self, model, device, target_rows: int = 50000):
+        self.model, self.device, self.target = model, device, target_rows
+        self.images, self.index, self.rows = [], [], 0
+
+    def _tokens_per_image(self, image):
+        clip = self.model.clip if hasattr(self.model, "clip") else self.model
+        g = getattr(getattr(clip, "visual", None), "grid_size", None)
+        per = (g[0] * g[1] + 1) if g else 50
+        return per * (image.shape[1] if image.dim() == 5 else 1)          # video clips: frames fold into the batch
+
+    def add(self, image, index):
+        """-> list of (index tensor on the device, embeddings) that became ready (possibly empty)."""
+        image = image.to(self.device, non_blocking=True)
+        self.images.append(image)
+        self.index.append(index.to(self.device).view(-1))
+        self.rows += image.shape[0] * self._tokens_per_image(image)
+        return self.flush() if self.rows >= self.target else []
+
+    def flush(self):
+        if not self.images:
+            return []
+        image = self.images[0] if len(self.images) == 1 else torch.cat(self.images, dim=0)
+        index = self.index[0] if len(self.index) == 1 else torch.cat(self.index)
+        self.images, self.index, self.rows = [], [], 0
+        with torch.no_grad():
+            return [(index, self.model.encode_image(image, normalize=True))]
+
+
 def _ln_grad_views(model):
     """Per-block dicts of the .grad tensors the backward kernels write into (allocated on demand)."""
     grads = []
@@ -262,18 +298,24 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     # its row shard of every replicated batch -- and ONE ragged all-gather at the end replicates the embeddings.
     with torch.no_grad():
         mine_idx, mine_emb = [], []
+        enc = GalleryEncoder(model, device)
+
+        def _place(ready):
+            for index, emb in ready:
+                if world == 1:
+                    all_image_embeds[index] = emb
+                else:
+                    mine_idx.append(index)
+                    mine_emb.append(emb)
+
         for image, index in data_loader_image:
             if world > 1 and not image_sharded:
                 lo, hi = _shard(len(index), world, rank)
                 if hi == lo:
                     continue
                 image, index = image[lo:hi], index[lo:hi]
-            emb = model.encode_image(image.to(device, non_blocking=True), normalize=True)
-            if world == 1:
-                all_image_embeds[index.to(device)] = emb
-            else:
-                mine_idx.append(index.to(device).view(-1))
-                mine_emb.append(emb)
+            _place(enc.add(image, index))
+        _place(enc.flush())
         if world > 1:
             idx_l = torch.cat(mine_idx) if mine_idx else torch.zeros(0, dtype=torch.int64, device=device)
             emb_l = torch.cat(mine_emb) if mine_emb else torch.zeros(0, D, device=device)

@@ -361,6 +361,16 @@ def test_patchify_and_vision_embed():
     assert torch.equal(p.cpu(), bf(O.patchify(img, patch).reshape(-1, K)))
     p2 = ops.patchify(img.to(DEV), patch, K + 64)
     assert torch.equal(p2.cpu()[:, :K], p.cpu()) and p2.cpu()[:, K:].float().abs().sum() == 0
+    # the three towers' geometries (float4 path: patch 32 / 16; float2 path: patch 14, K = 588 padded to 640), an
+    # odd patch size (scalar path) and an image view at an unaligned address (scalar path)
+    for HH, pp, kpad in ((224, 32, 3072), (224, 16, 768), (224, 14, 640), (45, 15, 768)):
+        im = torch.randn(2, 3, HH, HH, generator=g(7))
+        got = ops.patchify(im.to(DEV), pp, kpad).cpu()
+        kk = 3 * pp * pp
+        assert torch.equal(got[:, :kk], bf(O.patchify(im, pp).reshape(-1, kk))) and got[:, kk:].float().abs().sum() == 0
+    flat = torch.randn(1 + 2 * 3 * 32 * 32, generator=g(8)).to(DEV)
+    view = flat[1:].view(2, 3, 32, 32)                               # 4-byte aligned only
+    assert torch.equal(ops.patchify(view, 16, 768).cpu(), bf(O.patchify(view.cpu(), 16).reshape(-1, 768)))
     P = (H // patch) ** 2
     pe = torch.randn(n * P, C, generator=g(2)); cls = torch.randn(C, generator=g(3))
     pos = torch.randn(P + 1, C, generator=g(4)); gam = torch.rand(C, generator=g(5)) + 0.5; bet = torch.randn(C, generator=g(6))
