@@ -91,6 +91,15 @@ int neat_gemm_bf16_t256(const uint16_t* A, const uint16_t* Wp, const float* bias
                         const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int epilogue,
                         void* stream);
 int neat_gemm_prefers_t256(int M, int N, int K, int epilogue);
+/* The residual GEMM with the FOLLOWING LayerNorm folded into its epilogue (open_clip/transformer.py:241-242: the residual
+ * add of out_proj / c_proj, then ln_2 / the next block's ln_1, :15-30): x_out f32 [M,N] = A Wl^T + bias + res;
+ * y bf16 [M,N] = LayerNorm(x_out) * gamma + beta (biased variance, eps inside the sqrt, fp32 statistics); mean, rstd f32 [M]
+ * as neat_ln_fwd saves them.  Saves the separate LayerNorm launch and its re-read of x_out.  Units of 64 rows x N columns
+ * (csrc/gemm_rowln.hip); N == 512 only, K % 128 == 0, K >= 256; Wp = neat_pack_weight_bf16 layout; res must not alias
+ * x_out.  Other widths: neat_gemm_bf16(NEAT_EPI_BIAS_RES_F32) + neat_ln_fwd. */
+int neat_gemm_bf16_res_ln(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, const float* gamma,
+                          const float* beta, float* x_out, uint16_t* y, float* mean, float* rstd, int M, int N, int K,
+                          float eps, void* stream);
 /* NEAT_EPI_BIAS_GELU on tile256 for a forward pass whose LAST rows have no backward pass (the `neg` captions of the TTA
  * step, reference train_TTA.py:35: coarse alignment runs under no_grad): out1 bf16 [M,N] = QuickGELU(A Wl^T + bias) for
  * all rows, the pre-activation out0 bf16 [out0_rows,N] only for the first out0_rows <= M rows. */

@@ -1,0 +1,250 @@
+// Residual GEMM with the FOLLOWING LayerNorm folded into its epilogue (round-3 prototype of the byte-cutting fusion).
+// Reference: x = x + out_proj(attn) followed by ln_2(x), and x = x + c_proj(mlp) followed by the next block's ln_1(x)
+// (open_clip/transformer.py:241-242, 15-30).
+//
+//   x_out[M,N] (f32) = A[M,K] . W[N,K]^T + bias + res          y[M,N] (bf16) = LayerNorm(x_out) * gamma + beta
+//   mean[M], rstd[M] (f32) = the row statistics the backward pass needs
+//
+// Unfused, LayerNorm is its own launch that re-reads x_out from HBM (4 B per element) to write y (2 B).  Folding it in needs
+// a whole ROW in one workgroup at epilogue time, so the unit is 64 rows x N columns (N = 512: 8 waves x 64 columns,
+// accumulator 4 column tiles x 4 row tiles = 64 VGPRs -- the same 32 Ki outputs per unit as the panel kernel's 128 x 256):
+//   * the 64-row sub-panel streams through LDS in [64 x 128-k] pieces (16 KiB, double buffered) filled by LDS-DMA by a
+//     rotating half of the waves, exactly as in gemm_panel_kernel; weight fragments come straight from L2 in the packed
+//     MFMA-fragment layout of neat_pack_weight_bf16 (a fragment now serves 4 row tiles instead of 8, and every A fragment
+//     read from LDS serves 4 MFMAs instead of 2);
+//   * epilogue: the lane adds its residual values to the accumulators (a lane holds 4 consecutive columns of one row per
+//     tile), stores x_out, and the row statistics are reduced in two rounds (mean, then the centred sum of squares -- the
+//     two-pass form of csrc/ln.hip) across the 4 lanes that share a row by shuffles and across the 8 waves through LDS.
+// N is fixed at 512 here (ViT-B text towers, the benchmark configuration); other widths take the two launches.
+#include "common.h"
+
+namespace neat {
+
+constexpr int R_THREADS = 512;
+constexpr int R_N = 512;                    // row width this kernel is built for
+constexpr int R_RT = 4;                     // row tiles per unit (64 rows)
+constexpr int R_NI = 4;                     // column tiles per wave (64 columns)
+constexpr int R_BKH = 128;                  // k extent of an LDS piece
+constexpr int R_PIECE = 64 * R_BKH * 2;     // 16 KiB
+constexpr int R_RED = 2 * R_PIECE;          // reduction scratch behind the two pieces: [2][8 waves][64 rows] floats
+constexpr int R_LDS = R_RED + 2 * 8 * 64 * 4;
+
+__device__ __forceinline__ void rglds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int OCC>
+__global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
+    const bf16_t* __restrict__ A, const uint4* __restrict__ Wp, const float* __restrict__ bias, const float* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ xout, bf16_t* __restrict__ y,
+    float* __restrict__ mean, float* __restrict__ rstd, int M, int K, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int N = R_N;
+    constexpr int ksteps = R_BKH >> 5;               // 4
+    constexpr int cpr = R_BKH >> 3;                  // 16-B chunks per LDS row (16)
+    constexpr int rpi = 64 / cpr;                    // rows per LDS-DMA wave-instruction (4)
+    constexpr int ninstr = 64 * cpr / 64;            // wave-instructions per piece (16)
+    constexpr int rowbytes = cpr * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    float* red = reinterpret_cast<float*>(lds + R_RED);
+
+    const int nsub = (M + 63) >> 6;
+    const int G = gridDim.x;
+    const int myunits = (nsub - (int)blockIdx.x + G - 1) / G;       // units blockIdx, blockIdx + G, ...
+    if (myunits <= 0) return;
+    const int nkh = K / R_BKH;
+    const int ksK = K >> 5;
+    const int J = myunits * nkh;
+
+    auto issue_piece = [&](int j) {
+        const int t = j / nkh;
+        const int kh = j - t * nkh;
+        const int row0 = ((int)blockIdx.x + t * G) << 6;
+        const uint32_t buf = lds_base + (j & 1) * R_PIECE;
+        const bf16_t* src = A + kh * R_BKH;
+        for (int q = (wave & 3); q < ninstr; q += 4) {
+            const int row = q * rpi + lane / cpr;
+            const int c = (lane % cpr) ^ (row & 15);
+            int gr = row0 + row;
+            gr = gr < M ? gr : M - 1;
+            rglds16(src + (long)gr * K + c * 8, buf + q * 1024);
+        }
+    };
+
+    if ((wave >> 2) == 0) issue_piece(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int nt0 = wave * R_NI;                                     // first of this wave's 4 column tiles
+    f32x4 acc[R_NI][R_RT];
+    for (int j = 0; j < J; ++j) {
+        const int tu = j / nkh;
+        const int kh = j - tu * nkh;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (j + 1 < J && (wave >> 2) == ((j + 1) & 1)) issue_piece(j + 1);
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + (nt0 + i) * 16 + fq * 4);
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) acc[i][t] = b0;
+            }
+        }
+        {
+            const char* abase = lds + (j & 1) * R_PIECE + fr * rowbytes;
+            const uint4* wp = Wp + ((long)nt0 * ksK + (long)kh * ksteps) * 64 + lane;
+            uint4 wn[R_NI];
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) wn[i] = wp[(long)i * ksK * 64];
+#pragma unroll
+            for (int kk = 0; kk < ksteps; ++kk) {
+                bf16x8 wf[R_NI];
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) wf[i] = __builtin_bit_cast(bf16x8, wn[i]);
+                if (kk + 1 < ksteps) {
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i) wn[i] = wp[(long)i * ksK * 64 + (kk + 1) * 64];
+                }
+                const int coff = ((kk * 4 + fq) ^ fr) * 16;
+                bf16x8 af[R_RT];
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) af[t] = *reinterpret_cast<const bf16x8*>(abase + t * 16 * rowbytes + coff);
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t)
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[t], acc[i][t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kh == nkh - 1) {
+            // ---- epilogue: x = acc + res, row statistics over all 512 columns, y = LN(x) ----
+            const int row0 = ((int)blockIdx.x + tu * G) << 6;
+            // lane: rows row0 + 16 t + fr, columns 64 wave + 16 i + 4 fq .. + 3
+            float s1[R_RT];
+#pragma unroll
+            for (int t = 0; t < R_RT; ++t) {
+                int m = row0 + t * 16 + fr;
+                const bool ok = m < M;
+                m = ok ? m : M - 1;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) {
+                    const long o = (long)m * N + wave * 64 + i * 16 + fq * 4;
+                    const float4 r = *reinterpret_cast<const float4*>(res + o);
+                    f32x4 v = acc[i][t];
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                    acc[i][t] = v;
+                    if (ok) *reinterpret_cast<float4*>(xout + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    s += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                s1[t] = s;
+            }
+            // the reduction scratch was last read two barriers ago (previous unit's second round): free
+            if (fq == 0) {
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) red[wave * 64 + t * 16 + fr] = s1[t];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            float mu[R_RT], s2[R_RT];
+#pragma unroll
+            for (int t = 0; t < R_RT; ++t) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += red[w * 64 + t * 16 + fr];
+                mu[t] = s * (1.0f / N);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) {
+                    f32x4 v = acc[i][t];
+                    v[0] -= mu[t]; v[1] -= mu[t]; v[2] -= mu[t]; v[3] -= mu[t];
+                    acc[i][t] = v;
+                    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                s2[t] = q;
+            }
+            if (fq == 0) {
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) red[512 + wave * 64 + t * 16 + fr] = s2[t];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            f32x4 g4[R_NI], b4[R_NI];
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) {
+                g4[i] = *reinterpret_cast<const f32x4*>(gamma + wave * 64 + i * 16 + fq * 4);
+                b4[i] = *reinterpret_cast<const f32x4*>(beta + wave * 64 + i * 16 + fq * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < R_RT; ++t) {
+                float q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) q += red[512 + w * 64 + t * 16 + fr];
+                const float rs = rsqrtf(q * (1.0f / N) + eps);
+                const int m = row0 + t * 16 + fr;
+                if (m < M) {
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i) {
+                        const f32x4 v = acc[i][t];
+                        const float o0 = v[0] * rs * g4[i][0] + b4[i][0], o1 = v[1] * rs * g4[i][1] + b4[i][1];
+                        const float o2 = v[2] * rs * g4[i][2] + b4[i][2], o3 = v[3] * rs * g4[i][3] + b4[i][3];
+                        *reinterpret_cast<uint2*>(y + (long)m * N + wave * 64 + i * 16 + fq * 4) =
+                            make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+                    }
+                    if (wave == 0 && fq == 0) {
+                        mean[m] = mu[t];
+                        rstd[m] = rs;
+                    }
+                }
+            }
+            // the next unit's first reduction write happens behind at least the two barriers of its first two pieces
+            // (nkh >= 2 is required below), i.e. after every wave has finished the reads above
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace neat
+
+using namespace neat;
+
+// out-projection / c_proj with the following LayerNorm folded in.  A bf16 [M,K]; Wp = neat_pack_weight_bf16 of the [512,K]
+// weight; bias, gamma, beta f32 [512]; res f32 [M,512] (must NOT alias x_out); outputs x_out f32 [M,512], y bf16 [M,512],
+// mean / rstd f32 [M].  K % 128 == 0, K >= 256.
+extern "C" int neat_gemm_bf16_res_ln(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
+                                     const float* gamma, const float* beta, float* x_out, uint16_t* y, float* mean,
+                                     float* rstd, int M, int N, int K, float eps, void* stream) {
+    NEAT_REQUIRE(A && Wp && bias && res && gamma && beta && x_out && y && mean && rstd, NEAT_ERR_ARG,
+                 "neat_gemm_bf16_res_ln: null pointer");
+    NEAT_REQUIRE(res != x_out, NEAT_ERR_ARG, "neat_gemm_bf16_res_ln: res must not alias x_out");
+    NEAT_REQUIRE(M > 0 && N == R_N && K >= 2 * R_BKH && K % R_BKH == 0, NEAT_ERR_SHAPE,
+                 "neat_gemm_bf16_res_ln: M=%d N=%d K=%d unsupported (N == %d, K %% 128 == 0, K >= 256)", M, N, K, R_N);
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_dynamic_lds((const void*)gemm_rowln_kernel<2>, R_LDS, &attr_done, "hipFuncSetAttribute(gemm_rowln)"))
+        return rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        cus = 256;
+    const int units = cdiv(M, 64);
+    const int grid = units < 2 * cus ? units : 2 * cus;
+    hipLaunchKernelGGL((gemm_rowln_kernel<2>), dim3(grid), dim3(R_THREADS), R_LDS, (hipStream_t)stream, A,
+                       reinterpret_cast<const uint4*>(Wp), bias, res, gamma, beta, x_out, reinterpret_cast<bf16_t*>(y), mean,
+                       rstd, M, K, eps);
+    NEAT_LAUNCH_CHECK("neat_gemm_bf16_res_ln");
+    return NEAT_OK;
+}

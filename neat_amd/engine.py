@@ -15,6 +15,7 @@ open_clip/transformer.py:188-243 (ResidualAttentionBlock), :502-547 (VisionTrans
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -22,6 +23,11 @@ import torch
 from . import lib, ops
 
 f32, bf16 = torch.float32, torch.bfloat16
+
+# rows up to which the LayerNorm after a residual GEMM is folded into that GEMM (Stack.forward, ops.gemm_res_ln).  OFF by
+# default (0): measured in round 3, the fused launch wins in isolation at the packed text batches' size but not inside the
+# step, and loses at full length (numbers at the call site and in DESIGN.md §4); NEAT_FUSE_LN_MAX_ROWS=<rows> turns it on.
+FUSE_LN_MAX_ROWS = int(os.environ.get("NEAT_FUSE_LN_MAX_ROWS", "0"))
 
 
 class BlockWeights:
@@ -55,18 +61,39 @@ class Stack:
         sequence).  With ``save`` a list, per-layer tensors needed by ``backward`` are appended (and x buffers
         are never overwritten).  grad_rows: only the first grad_rows rows will see a backward pass (the MLP
         pre-activation of the other rows is not kept)."""
-        for w in self.blocks:
-            y, _, mu1, rs1 = ops.ln_fwd(x, w.ln1_w, w.ln1_b, save_stats=save is not None)
-            qkv, _ = ops.gemm(y, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
-            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=save is not None, cu=cu, head_major=True)
-            x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
-            y, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=save is not None)
-            h, u = ops.gemm(y, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"],
+        # The LayerNorm that follows a residual GEMM (ln_2 after the out-projection, the NEXT block's ln_1 after c_proj) is
+        # folded into that GEMM's epilogue (ops.gemm_res_ln, csrc/gemm_rowln.hip) when FUSE_LN_MAX_ROWS allows it (width 512
+        # only).  Measured (tools/rowln_bench.py, profiles/r03_rowln_*): in isolation at 14 848 rows the out-projection
+        # 46.6 vs 50.7 us and c_proj 79.7 vs 90.6 us for GEMM + LayerNorm; inside the packed step the fused launches average
+        # 68.7 us against 56.7 + 9.3 us (the 64-row unit re-reads the weights twice as often, and in the step they are not
+        # L2-resident): 16.7 vs 15.9 ms per batch; at 78 848 rows 173.5 vs 144.5 us and 296 vs 251 us.  So: off.
+        rows, C = x.shape
+        fuse = FUSE_LN_MAX_ROWS > 0 and rows <= FUSE_LN_MAX_ROWS and ops.gemm_res_ln_ok(C, C)
+        stats = save is not None
+        w0 = self.blocks[0]
+        y1, _, mu1, rs1 = ops.ln_fwd(x, w0.ln1_w, w0.ln1_b, save_stats=stats)
+        for k, w in enumerate(self.blocks):
+            nxt = self.blocks[k + 1] if k + 1 < len(self.blocks) else None
+            qkv, _ = ops.gemm(y1, w.w["qkv"], lib.EPI_BIAS_BF16, bias=w.b["qkv"])
+            o, lse = ops.attn_fwd(qkv, nseq, L, self.heads, self.causal, save_lse=stats, cu=cu, head_major=True)
+            if fuse:
+                x1, y2, mu2, rs2 = ops.gemm_res_ln(o, w.w["o"], w.b["o"], x, w.ln2_w, w.ln2_b)
+            else:
+                x1, _ = ops.gemm(o, w.w["o"], lib.EPI_BIAS_RES_F32, bias=w.b["o"], res=x)
+                y2, _, mu2, rs2 = ops.ln_fwd(x1, w.ln2_w, w.ln2_b, save_stats=stats)
+            h, u = ops.gemm(y2, w.w["fc"], lib.EPI_BIAS_GELU, bias=w.b["fc"],
                             out0_rows=grad_rows if save is not None else 0)
-            x2, _ = ops.gemm(u, w.w["proj"], lib.EPI_BIAS_RES_F32, bias=w.b["proj"], res=x1)
+            if fuse and nxt is not None and ops.gemm_res_ln_ok(C, u.shape[1]):
+                x2, y1n, mu1n, rs1n = ops.gemm_res_ln(u, w.w["proj"], w.b["proj"], x1, nxt.ln1_w, nxt.ln1_b)
+            else:
+                x2, _ = ops.gemm(u, w.w["proj"], lib.EPI_BIAS_RES_F32, bias=w.b["proj"], res=x1)
+                if nxt is not None:
+                    y1n, _, mu1n, rs1n = ops.ln_fwd(x2, nxt.ln1_w, nxt.ln1_b, save_stats=stats)
             if save is not None:
                 save.append(dict(x0=x, mu1=mu1, rs1=rs1, qkv=qkv, lse=lse, x1=x1, mu2=mu2, rs2=rs2, h=h))
             x = x2
+            if nxt is not None:
+                y1, mu1, rs1 = y1n, mu1n, rs1n
         return x
 
     def backward(self, dxf, dxb, nseq: int, L: int, saved: list, grads: List[Dict[str, torch.Tensor]],

@@ -29,6 +29,7 @@ SIGNATURES = {
     "neat_pack_weight_bf16_t256": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_gemm_bf16_t256": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "neat_gemm_prefers_t256": (_I, [_I, _I, _I, _I]),
+    "neat_gemm_bf16_res_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "neat_gemm_bf16_t256_gelu_rows": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "neat_image_preprocess_ws_bytes": (_L, [_I, _I, _I]),
     "neat_image_preprocess": (_I, [_P, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _P, _P]),

@@ -13,6 +13,7 @@ Host-side integer work, not accelerated: a batch of 25
 from __future__ import annotations
 
 import gzip
+from itertools import chain as _chain_cls
 import html
 import os
 import re as _re
@@ -21,6 +22,7 @@ from typing import List, Optional, Union
 import numpy as np
 import torch
 
+_chain = _chain_cls.from_iterable
 DEFAULT_CONTEXT_LENGTH = 77
 N_MERGES = 49152 - 256 - 2
 
@@ -105,6 +107,7 @@ class SimpleTokenizer:
         self.context_length = context_length
         self._cache = {}
         self._ids = {}                  # pre-token (as matched by the regex) -> list of vocabulary ids
+        self._words = {}                # whitespace-delimited lower-cased ASCII word -> list of vocabulary ids
 
     def _merge(self, token: str) -> List[str]:
         """Greedy BPE of one pre-token (already in byte symbols): repeatedly fuse every occurrence of the adjacent
@@ -137,7 +140,7 @@ class SimpleTokenizer:
         self._cache[token] = out
         return out
 
-    def encode(self, text: str) -> List[int]:
+    def _encode_slow(self, text: str) -> List[int]:
         ids = []
         known = self._ids
         for tok in self.pat.findall(_clean_lower(text)):
@@ -145,6 +148,36 @@ class SimpleTokenizer:
             if hit is None:
                 sym = "".join(self.sym[b] for b in tok.encode("utf-8"))
                 hit = known[tok] = [self.encoder[p] for p in self._merge(sym)]
+            ids.extend(hit)
+        return ids
+
+    def _word_ids(self, word: str):
+        """ids of one whitespace-delimited, lower-cased word, or None when the word needs the full cleaning path (anything
+        but printable ASCII, or a character that html.unescape / the special-token alternatives could act on)."""
+        if not (word.isascii() and word.isprintable()) or "&" in word or "<" in word:
+            return None
+        return self._encode_slow(word)
+
+    def encode(self, text: str) -> List[int]:
+        """Fast path for plain captions: cleaning (whitespace runs -> one space, lower-casing) and the pre-tokenising regex
+        never look across whitespace, and on printable ASCII without '&' / '<' neither ftfy nor html.unescape nor the
+        special-token alternatives change anything -- so a caption is the concatenation of its words' ids, and words come
+        from a cache (no regex call at all for a known word: 16.7 -> 4 ms per 4 x 256 captions).  Any other word sends
+        the whole caption through the full path."""
+        cache = self._words
+        words = text.lower().split()
+        try:                                              # every word known: the whole caption in C-level loops
+            return list(_chain(map(cache.__getitem__, words)))
+        except KeyError:
+            pass
+        ids = []
+        for w in words:
+            hit = cache.get(w)
+            if hit is None:
+                hit = self._word_ids(w)
+                if hit is None:
+                    return self._encode_slow(text)
+                cache[w] = hit
             ids.extend(hit)
         return ids
 
@@ -159,13 +192,24 @@ class SimpleTokenizer:
         n = context_length or self.context_length
         if not n:
             raise ValueError("SimpleTokenizer: context_length must be set")
-        out = np.zeros((len(texts), n), dtype=np.int64)          # one array, filled row by row: no per-caption tensors
-        for i, text in enumerate(texts):
-            ids = [self.sot_token_id] + self.encode(text) + [self.eot_token_id]
-            if len(ids) > n:
-                ids = ids[:n]
-                ids[-1] = self.eot_token_id
-            out[i, :len(ids)] = ids
+        # one array for the batch, filled by ONE scatter: ids of all captions back to back + their (row, column) positions
+        sot, eot = self.sot_token_id, self.eot_token_id
+        rows_ids = []
+        for text in texts:
+            ids = self.encode(text)
+            if len(ids) > n - 2:                          # truncation keeps EOT last (reference tokenizer.py:250-259)
+                ids = ids[:n - 2]
+            rows_ids.append(ids)
+        lens = np.fromiter(map(len, rows_ids), dtype=np.int64, count=len(rows_ids))
+        out = np.zeros((len(texts), n), dtype=np.int64)
+        out[:, 0] = sot
+        out[np.arange(len(texts)), lens + 1] = eot
+        total = int(lens.sum())
+        if total:
+            flat = np.fromiter(_chain(rows_ids), dtype=np.int64, count=total)
+            starts = np.cumsum(lens) - lens
+            rows = np.repeat(np.arange(len(texts)), lens)
+            out[rows, np.arange(total) - np.repeat(starts, lens) + 1] = flat
         return torch.from_numpy(out)
 
 

@@ -231,6 +231,30 @@ def gemm(A, W: PackedWeight, epilogue, bias=None, res=None, aux=None, out0=None,
     return out0, out1
 
 
+def gemm_res_ln_ok(N, K):
+    return N == 512 and K % 128 == 0 and K >= 256
+
+
+def gemm_res_ln(A, W: PackedWeight, bias, res, gamma, beta, eps=1e-5):
+    """x_out = A @ Wl^T + bias + res (fp32) and y = LayerNorm(x_out) * gamma + beta (bf16) in ONE launch
+    (neat_gemm_bf16_res_ln) -> (x_out, y, mean, rstd)."""
+    M, K = A.shape
+    N = W.N
+    if W.K != K or not gemm_res_ln_ok(N, K):
+        raise RuntimeError(f"gemm_res_ln: unsupported shape {tuple(A.shape)} x packed [{W.N},{W.K}]")
+    if tuple(res.shape) != (M, N) or res.dtype != f32:
+        raise RuntimeError("gemm_res_ln: residual must be float32 [M, N]")
+    dev = A.device
+    x_out = torch.empty(M, N, dtype=f32, device=dev)
+    y = torch.empty(M, N, dtype=bf16, device=dev)
+    mean = torch.empty(M, dtype=f32, device=dev)
+    rstd = torch.empty(M, dtype=f32, device=dev)
+    lib.call("neat_gemm_bf16_res_ln", _p(A, bf16, "A"), _p(W.data, bf16, "W"), _p(bias, f32, "bias"), _p(res, f32, "res"),
+             _p(gamma, f32, "gamma"), _p(beta, f32, "beta"), _p(x_out), _p(y), _p(mean), _p(rstd), M, N, K, float(eps),
+             _stream())
+    return x_out, y, mean, rstd
+
+
 # ---- image preprocessing ----
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)

@@ -143,6 +143,36 @@ def test_gemm_epilogues(M, N, K, kern):
     assert rel_l2(o.float().cpu(), ref * O.quick_gelu_grad(aux.float())) < tol
 
 
+@pytest.mark.parametrize("M,K", [(64 * 37 + 5, 256), (14848, 512), (1000, 2048), (40000, 512)])
+def test_gemm_res_ln_equals_gemm_then_layernorm(M, K):
+    """neat_gemm_bf16_res_ln (residual GEMM + the LayerNorm that follows it, one launch, 64 x 512 units) against the two
+    launches it replaces: x_out bit-identical to the panel kernel's BIAS_RES_F32 result (same MFMA order per output), the
+    statistics and y = LN(x_out) equal to neat_ln_fwd on that x_out up to the summation order of the row reductions (a
+    bf16 value may land on the neighbouring grid point), and both against the fp32 reference."""
+    N = 512
+    A = bf(torch.randn(M, K, generator=g(1)))
+    W = bf(torch.randn(N, K, generator=g(2)) * K ** -0.5)
+    bias = torch.randn(N, generator=g(3)) * 0.1
+    res = torch.randn(M, N, generator=g(4))
+    gam = 1 + 0.2 * torch.randn(N, generator=g(5))
+    bet = 0.1 * torch.randn(N, generator=g(6))
+    Ad, Wd = A.to(DEV), ops.pack_weight(W.float().to(DEV))
+    x, y, mu, rs = ops.gemm_res_ln(Ad, Wd, bias.to(DEV), res.to(DEV), gam.to(DEV), bet.to(DEV))
+    x2, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bias.to(DEV), res=res.to(DEV), kernel="panel")
+    assert torch.equal(x, x2)
+    y2, _, mu2, rs2 = ops.ln_fwd(x2, gam.to(DEV), bet.to(DEV))
+    assert rel_l2(mu.cpu(), mu2.cpu()) < 1e-5 and rel_l2(rs.cpu(), rs2.cpu()) < 1e-6
+    d = (y.float() - y2.float()).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and rel_l2(y.float().cpu(), y2.float().cpu()) < 1e-4
+    ref = A.float() @ W.float().t() + bias + res
+    assert rel_l2(x.cpu(), ref) < 1e-5
+    yr, mr, rr = O.layer_norm_fwd(ref, gam, bet)
+    assert rel_l2(y.float().cpu(), yr) < 4e-3 and rel_l2(rs.cpu(), rr) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.gemm_res_ln(Ad[:, :128].contiguous(), ops.pack_weight(W.float()[:, :128].contiguous().to(DEV)), bias.to(DEV),
+                        res.to(DEV), gam.to(DEV), bet.to(DEV))              # K = 128: not supported
+
+
 def test_gemm_exact_small_integers():
     """A = I (padded) with an ASYMMETRIC integer W catches a transposed C write or a wrong k order."""
     M = N = 256

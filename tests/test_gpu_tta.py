@@ -421,11 +421,14 @@ def test_gradient_error_attribution(spread):
     assert rep["grad_rel_backward_only"] <= rel_max, rep
 
 
-def test_train_one_epoch_dropin_matches_manual_loop():
-    """The public entry point (same signature as the reference) == the hand-stepped loop, bit for bit."""
-    r = _run_hip_manual("tiny")
+@pytest.mark.parametrize("packed", [False, True])
+def test_train_one_epoch_dropin_matches_manual_loop(packed):
+    """The public entry point (same signature as the reference) == the hand-stepped loop, bit for bit, with the packed
+    text batches (the default) and with all context_length positions."""
+    r = _run_hip_manual("tiny", packed)
     m = r["m"]
     model, _ = _model(m["model"], m["wseed"])
+    model.pack_tokens = packed
     oc.freeze_parameters(model, False)
     params, _ = oc.collect_params(model, False)
     opt = AdamW(params, lr=m["lr"], weight_decay=m["wd"])

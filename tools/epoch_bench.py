@@ -21,9 +21,9 @@ PAT = re.compile(r"[a-z]+|[0-9]|[^\sa-z0-9]+")
 _ids = {}
 
 
-# the real SimpleTokenizer measures 22 ms per 4 x 256 captions on this host class (88 ms before this round's fixes);
-# TOK_MS pads every call of the stand-in to that cost (per caption set) with a busy wait
-TOK_MS = float(os.environ.get("TOK_MS", 5.5))
+# the real SimpleTokenizer measures 5.4 ms per 4 x 256 captions on this host class since round 3 (word cache: 16.7-22 ms in
+# round 2, 88 ms before that); TOK_MS pads every call of the stand-in to that cost (per caption set) with a busy wait
+TOK_MS = float(os.environ.get("TOK_MS", 1.4))
 
 
 def tokenizer(texts):
@@ -71,6 +71,9 @@ print(f"tokenizer stand-in: {(time.perf_counter() - t0) / 4 * 1e3:.1f} ms per ba
 
 model = oc.create_model("ViT-B-32", device=DEV)
 model.load_state_dict(synth.synth_state_dict("ViT-B-32", 0))
+if os.environ.get("PACK") is not None:
+    model.pack_tokens = os.environ["PACK"] != "0"
+print(f"pack_tokens = {model.pack_tokens}", flush=True)
 oc.freeze_parameters(model, False)
 opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
 args = types.SimpleNamespace(distributed=False, tta_only_visual=False, name="neat", tta_steps=3, tta_temperature=0.03,
