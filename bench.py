@@ -31,12 +31,12 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0             # HBM3E peak, same guide
-# HBM traffic per launch of the c_fc GEMM from the PMC counters (profiles/r02_bench_pmc_*.csv: separate
+# HBM traffic per launch of the c_fc GEMM from the PMC counters (profiles/r03_bench_pmc_*.csv, unchanged from r02: separate
 # `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same command; counters are in KiB;
 # FETCH_SIZE doubled as the guide prescribes for gfx950 wide streaming reads -- the LN kernels in the same
 # passes confirm the factor: ln_fwd reports 80.8 MB for a 161.5 MB read).  Keyed by (M, N, K); a launch mix
 # that was not profiled reports traffic = null.
-PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 119722.27 + 551936.00) * 1024)}
+PMC_TRAFFIC_BYTES = {(78848, 2048, 512): int((2 * 119672.57 + 551936.00) * 1024)}
 
 
 def parse():
