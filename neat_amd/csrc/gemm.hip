@@ -103,7 +103,7 @@ __device__ __forceinline__ void piece_mma(f32x4 (&acc)[NI][8], const uint4* __re
 template <int EPI, int BKH, int NI, int OCC>
 __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
     const bf16_t* __restrict__ A, const uint4* __restrict__ Wp, const float* __restrict__ bias, const float* res,
-    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K) {
+    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K, int warm) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int ksteps = BKH >> 5;                 // MFMA k-steps per piece (4 or 8)
     constexpr int cpr = BKH >> 3;                    // 16-B chunks per LDS row (16 or 32)
@@ -155,8 +155,25 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
         }
     };
 
+    // W warm-up.  The weights of a launch are not L2-resident when it starts (a layer alternates eight weight matrices and
+    // streams its activations through the same 4-MB L2s), and the main loop meets them one 128-k slice at a time: every
+    // piece starts with L2 misses that all workgroups of an XCD take together.  So the workgroups of an XCD first touch the
+    // WHOLE packed weight between them, one 16-B load per lane and 8 KiB per workgroup and pass (results discarded): one
+    // bulk fetch from HBM / the Infinity Cache instead of K / 128 dependent ones.  Retired by the vmcnt(0) below.
+    // The loads are asynchronous: their destination registers stay reserved (one live value, tied through every asm and read
+    // once after the wait) until the vmcnt(0) has retired them -- a discarded "=v" output would let the compiler hand
+    // the registers to something else while the loads are still in flight.
+    typedef unsigned warm_u32x4 __attribute__((ext_vector_type(4)));
+    warm_u32x4 warmv = {0u, 0u, 0u, 0u};
+    if (warm) {
+        const long wbytes = (long)N * K * 2;
+        const char* wbase = reinterpret_cast<const char*>(Wp);
+        for (long off = ((long)wg * P_THREADS + threadIdx.x) * 16; off < wbytes; off += (long)WX * P_THREADS * 16)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(warmv) : "v"(wbase + off) : "memory");
+    }
     if ((wave >> 2) == 0) issue_piece(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("; warm-up retired" :: "v"(warmv));
 
     f32x4 acc[NI][8];
     for (int j = 0; j < J; ++j) {
@@ -382,6 +399,16 @@ static int num_cus() {
     return g_num_cu;
 }
 
+// NEAT_GEMM_WARM_W=0 switches the weight warm-up of both kernels off (A/B measurements; read once per process)
+static int warm_w_enabled() {
+    static int warm = -1;
+    if (warm < 0) {
+        const char* e = getenv("NEAT_GEMM_WARM_W");
+        warm = e ? (atoi(e) != 0) : 1;
+    }
+    return warm;
+}
+
 template <int EPI, int BKH, int NI, int OCC>
 static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                          const uint16_t* aux, void* out0, void* out1, int M, int N, int K, int grid, hipStream_t s) {
@@ -390,8 +417,9 @@ static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bia
     if (int rc = ensure_dynamic_lds((const void*)gemm_panel_kernel<EPI, BKH, NI, OCC>, ldsb, &attr_done,
                                     "hipFuncSetAttribute(gemm)"))
         return rc;
+    const int warm = warm_w_enabled();
     hipLaunchKernelGGL((gemm_panel_kernel<EPI, BKH, NI, OCC>), dim3(grid), dim3(P_THREADS), ldsb, s, A,
-                       reinterpret_cast<const uint4*>(Wp), bias, res, aux, out0, out1, M, N, K);
+                       reinterpret_cast<const uint4*>(Wp), bias, res, aux, out0, out1, M, N, K, warm);
     NEAT_LAUNCH_CHECK("neat_gemm_bf16");
     return NEAT_OK;
 }
@@ -462,7 +490,7 @@ __host__ __device__ constexpr bool t256_shape_ok(int N, int K) { return N % 256 
 template <int EPI>
 __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
     const bf16_t* __restrict__ A, const char* __restrict__ Wp, const float* __restrict__ bias, const float* res,
-    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K, int rows0) {
+    const bf16_t* __restrict__ aux, void* out0, void* out1, int M, int N, int K, int rows0, int warm) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool PERM = !(EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_F32);   // bf16 outputs
     constexpr bool HAS_BIAS = EPI == NEAT_EPI_BIAS_BF16 || EPI == NEAT_EPI_BIAS_RES_F32 || EPI == NEAT_EPI_BIAS_GELU;
@@ -558,6 +586,17 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
         }                                                          // else: hold the last K-tile (harmless re-reads)
     };
 
+    // W warm-up, as in gemm_panel_kernel: the workgroups of an XCD touch the whole packed weight between them before the
+    // first K-tile, so that the K-tile stream meets it in L2.  Issued BEFORE the prologue's LDS-DMA: loads retire in
+    // order, so the counted vmcnt(6) below has retired these too; the destination registers stay reserved until then.
+    typedef unsigned warm_u32x4 __attribute__((ext_vector_type(4)));
+    warm_u32x4 warmv = {0u, 0u, 0u, 0u};
+    if (warm) {
+        const long wbytes = (long)N * K * 2;
+        for (long off = ((long)wg * T_THREADS + threadIdx.x) * 16; off < wbytes; off += (long)WX * T_THREADS * 16)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(warmv) : "v"(Wp + off) : "memory");
+    }
+
     // prologue: K-tile 0 whole, K-tile 1 without its A1 (7 half-tiles, 14 LDS-DMA per wave)
     stage_a(0, 0, s1_row0, 0);
     stage_b(0, 0, s1_wb, 0);
@@ -570,6 +609,7 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tile256_kernel(
     s2_t = s1_t, s2_kt = s1_kt, s2_row0 = s1_row0, s2_wb = s1_wb;
     advance(s2_t, s2_kt, s2_row0, s2_wb);                          // s2 -> K-tile 2
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               // K-tile 0 has landed (this wave's share)
+    asm volatile("; warm-up retired" :: "v"(warmv));
     __syncthreads();                                               // ... everybody's; bias copy visible
     if (wr == 1) T_BARRIER();                                      // wave row 1 runs one barrier behind row 0
 
@@ -844,7 +884,8 @@ static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* 
     const long want = (units + 7) / 8 * 8;
     const int grid = (int)(want < cus ? want : cus);
     hipLaunchKernelGGL((gemm_tile256_kernel<EPI>), dim3(grid), dim3(T_THREADS), T_LDS, s, A,
-                       reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K, rows0 < 0 ? M : rows0);
+                       reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K, rows0 < 0 ? M : rows0,
+                       warm_w_enabled());
     NEAT_LAUNCH_CHECK("neat_gemm_bf16(tile256)");
     return NEAT_OK;
 }
