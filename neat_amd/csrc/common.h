@@ -75,6 +75,14 @@ int check_hip(hipError_t e, const char* what);
 // loss.hip: C[M,N] = A[M,K] . B[N,K]^T, exact fp32 FMA chains in k order; K % 16 == 0
 int launch_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, long ldc, hipStream_t s);   // ldc: row pitch of C (floats)
 
+// gemm_rowln.hip: the 64 x 512-unit GEMM for N = 512 launches of at most one 128 x 256 unit per CU (fp32 residual and
+// plain bf16 epilogues; same packed weights and bit-identical results as gemm_panel_kernel)
+bool gemm_wide512_applies(int M, int N, int K, int epilogue);
+// gemm.hip: 0 when NEAT_GEMM_WARM_W=0 switched the weight warm-up of the GEMM kernels off (A/B measurements), else 1
+int gemm_warm_w_enabled();
+int launch_gemm_wide512(int epilogue, const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, void* out0,
+                        int M, int K, hipStream_t s);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember it per device (bit d of `done`),
 // not per process.  Call before launching `fn` with more than 64 KiB of dynamic LDS.
 int ensure_dynamic_lds(const void* fn, int bytes, unsigned long long* done, const char* what);

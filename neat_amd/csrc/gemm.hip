@@ -400,7 +400,7 @@ static int num_cus() {
 }
 
 // NEAT_GEMM_WARM_W=0 switches the weight warm-up of both kernels off (A/B measurements; read once per process)
-static int warm_w_enabled() {
+int gemm_warm_w_enabled() {
     static int warm = -1;
     if (warm < 0) {
         const char* e = getenv("NEAT_GEMM_WARM_W");
@@ -417,7 +417,7 @@ static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bia
     if (int rc = ensure_dynamic_lds((const void*)gemm_panel_kernel<EPI, BKH, NI, OCC>, ldsb, &attr_done,
                                     "hipFuncSetAttribute(gemm)"))
         return rc;
-    const int warm = warm_w_enabled();
+    const int warm = gemm_warm_w_enabled();
     hipLaunchKernelGGL((gemm_panel_kernel<EPI, BKH, NI, OCC>), dim3(grid), dim3(P_THREADS), ldsb, s, A,
                        reinterpret_cast<const uint4*>(Wp), bias, res, aux, out0, out1, M, N, K, warm);
     NEAT_LAUNCH_CHECK("neat_gemm_bf16");
@@ -429,6 +429,9 @@ static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias,
                        const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
     const int cus = num_cus();
     const long units = (long)cdiv(M, 128) * cdiv(N, P_WAVES * P_NI * 16);
+    // N = 512 at no more than one unit per CU (packed text batches, the MCQ scorer): the 64 x 512-unit kernel
+    if (gemm_wide512_applies(M, N, K, EPI))
+        return launch_gemm_wide512(EPI, A, Wp, bias, res, out0, M, K, s);
     // persistent: two workgroups per CU; a multiple of 8 so that the XCD-aware deal applies
     const long want = (units + 7) / 8 * 8;
     const int grid = (int)(want < 2 * cus ? want : 2 * cus);
@@ -885,7 +888,7 @@ static int launch_gemm_t256(const uint16_t* A, const uint16_t* Wp, const float* 
     const int grid = (int)(want < cus ? want : cus);
     hipLaunchKernelGGL((gemm_tile256_kernel<EPI>), dim3(grid), dim3(T_THREADS), T_LDS, s, A,
                        reinterpret_cast<const char*>(Wp), bias, res, aux, out0, out1, M, N, K, rows0 < 0 ? M : rows0,
-                       warm_w_enabled());
+                       gemm_warm_w_enabled());
     NEAT_LAUNCH_CHECK("neat_gemm_bf16(tile256)");
     return NEAT_OK;
 }

@@ -16,6 +16,18 @@
 //     tile), stores x_out, and the row statistics are reduced in two rounds (mean, then the centred sum of squares -- the
 //     two-pass form of csrc/ln.hip) across the 4 lanes that share a row by shuffles and across the 8 waves through LDS.
 // N is fixed at 512 here (ViT-B text towers, the benchmark configuration); other widths take the two launches.
+//
+// The same 64 x 512 structure WITHOUT the LayerNorm (MODE W_RES: fp32 residual epilogue; W_BF16: plain bf16 output through
+// wave-private LDS slabs, whole 128-B lines) serves the N = 512 GEMMs of launches that put at most one 128 x 256 unit on a
+// CU -- the packed text batches, the MCQ scorer (neat_gemm_bf16 sends them here, gemm_wide512_applies).  Every A fragment
+// read from LDS feeds four MFMAs instead of two (the panel kernel's 32-column wave tile keeps the LDS pipe as busy as the
+// matrix pipe), but every weight fragment is read twice as often: the shape wins only while W is L2-resident (one GEMM
+// repeated: out-projection 35.7 vs 40.8 us, c_proj 64.2 vs 81.6 us at 14 848 rows, tools/rowln_bench.py).  Inside the step
+// that is what the weight warm-up at kernel start buys (see gemm_panel_kernel): with it the packed step gains 2.9 %
+// (15.08 -> 14.65 ms per batch of 256, tools/experiments/wide_ab.sh); without it the same dispatch was neutral.  At 78 848
+// rows the panel kernel's longer weight reuse wins (104.8 vs 131.6 us) and keeps those launches.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace neat {
@@ -27,7 +39,9 @@ constexpr int R_NI = 4;                     // column tiles per wave (64 columns
 constexpr int R_BKH = 128;                  // k extent of an LDS piece
 constexpr int R_PIECE = 64 * R_BKH * 2;     // 16 KiB
 constexpr int R_RED = 2 * R_PIECE;          // reduction scratch behind the two pieces: [2][8 waves][64 rows] floats
-constexpr int R_LDS = R_RED + 2 * 8 * 64 * 4;
+constexpr int R_SLAB = R_RED + 2 * 8 * 64 * 4;   // eight wave-private 2-KiB slabs (bf16 epilogue: 16 rows x 128 B)
+constexpr int R_LDS = R_SLAB + 8 * 2048;
+enum { W_LN = 0, W_RES = 1, W_BF16 = 2 };
 
 __device__ __forceinline__ void rglds16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
@@ -42,11 +56,11 @@ __device__ __forceinline__ void rglds16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
-template <int OCC>
-__global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
+template <int MODE>
+__global__ __launch_bounds__(R_THREADS, 4) void gemm_rowln_kernel(
     const bf16_t* __restrict__ A, const uint4* __restrict__ Wp, const float* __restrict__ bias, const float* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ xout, bf16_t* __restrict__ y,
-    float* __restrict__ mean, float* __restrict__ rstd, int M, int K, float eps) {
+    float* __restrict__ mean, float* __restrict__ rstd, int M, int K, float eps, int warm) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int N = R_N;
     constexpr int ksteps = R_BKH >> 5;               // 4
@@ -83,8 +97,20 @@ __global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
         }
     };
 
+    // W warm-up (see gemm_panel_kernel): the workgroups of an XCD touch the whole packed weight between them
+    typedef unsigned warm_u32x4 __attribute__((ext_vector_type(4)));
+    warm_u32x4 warmv = {0u, 0u, 0u, 0u};
+    if (warm) {
+        const int xcd = blockIdx.x & 7;                             // round-robin placement (speed only)
+        const long wg = blockIdx.x >> 3, WX = (G - xcd + 7) >> 3;   // this workgroup among the WX of its XCD
+        const long wbytes = (long)N * K * 2;
+        const char* wbase = reinterpret_cast<const char*>(Wp);
+        for (long off = (wg * R_THREADS + threadIdx.x) * 16; off < wbytes; off += WX * R_THREADS * 16)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(warmv) : "v"(wbase + off) : "memory");
+    }
     if ((wave >> 2) == 0) issue_piece(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("; warm-up retired" :: "v"(warmv));
 
     const int nt0 = wave * R_NI;                                     // first of this wave's 4 column tiles
     f32x4 acc[R_NI][R_RT];
@@ -96,7 +122,8 @@ __global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
         if (kh == 0) {
 #pragma unroll
             for (int i = 0; i < R_NI; ++i) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + (nt0 + i) * 16 + fq * 4);
+                f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE != W_BF16) b0 = *reinterpret_cast<const f32x4*>(bias + (nt0 + i) * 16 + fq * 4);
 #pragma unroll
                 for (int t = 0; t < R_RT; ++t) acc[i][t] = b0;
             }
@@ -129,8 +156,33 @@ __global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (kh == nkh - 1) {
-            // ---- epilogue: x = acc + res, row statistics over all 512 columns, y = LN(x) ----
             const int row0 = ((int)blockIdx.x + tu * G) << 6;
+            if constexpr (MODE == W_BF16) {
+                // bf16 output: the wave's 16 x 64 tile of a row tile is 16 rows x 128 B; through the wave-private slab it
+                // leaves as whole lines (8 rows x 128 B per instruction).  16-B chunks XOR-swizzled by the row.
+                char* slab = lds + R_SLAB + wave * 2048;
+                bf16_t* out = y;
+                const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) {
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i) {
+                        const f32x4 v = acc[i][t];
+                        // lane's 8 bytes: columns 16 i + 4 fq .. + 3 -> byte 32 i + 8 fq of the row = chunk 2 i + (fq >> 1)
+                        char* p = slab + fr * 128 + (((2 * i + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8;
+                        *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r = rr + 8 * h;
+                        const uint4 q = *reinterpret_cast<const uint4*>(slab + r * 128 + ((cc ^ (r & 7)) << 4));
+                        const int m = row0 + t * 16 + r;
+                        if (m < M) *reinterpret_cast<uint4*>(out + (long)m * N + wave * 64 + cc * 8) = q;
+                    }
+                }
+                continue;
+            }
+            // ---- epilogue: x = acc + res, row statistics over all 512 columns, y = LN(x) ----
             // lane: rows row0 + 16 t + fr, columns 64 wave + 16 i + 4 fq .. + 3
             float s1[R_RT];
 #pragma unroll
@@ -153,6 +205,7 @@ __global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
                 s += __shfl_xor(s, 32, 64);
                 s1[t] = s;
             }
+            if constexpr (MODE == W_RES) continue;            // residual GEMM without the LayerNorm: done
             // the reduction scratch was last read two barriers ago (previous unit's second round): free
             if (fq == 0) {
 #pragma unroll
@@ -222,6 +275,30 @@ __global__ __launch_bounds__(R_THREADS, 2 * OCC) void gemm_rowln_kernel(
 
 using namespace neat;
 
+static int wide_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+        cus = 256;
+    return cus;
+}
+
+template <int MODE>
+static int launch_wide(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, const float* gamma,
+                       const float* beta, float* x_out, uint16_t* y, float* mean, float* rstd, int M, int K, float eps,
+                       hipStream_t s, const char* what) {
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_dynamic_lds((const void*)gemm_rowln_kernel<MODE>, R_LDS, &attr_done, "hipFuncSetAttribute(gemm_rowln)"))
+        return rc;
+    const int cus = wide_cus();
+    const int units = cdiv(M, 64);
+    const int grid = units < 2 * cus ? units : 2 * cus;
+    hipLaunchKernelGGL((gemm_rowln_kernel<MODE>), dim3(grid), dim3(R_THREADS), R_LDS, s, A, reinterpret_cast<const uint4*>(Wp),
+                       bias, res, gamma, beta, x_out, reinterpret_cast<bf16_t*>(y), mean, rstd, M, K, eps, gemm_warm_w_enabled());
+    NEAT_LAUNCH_CHECK(what);
+    return NEAT_OK;
+}
+
 // out-projection / c_proj with the following LayerNorm folded in.  A bf16 [M,K]; Wp = neat_pack_weight_bf16 of the [512,K]
 // weight; bias, gamma, beta f32 [512]; res f32 [M,512] (must NOT alias x_out); outputs x_out f32 [M,512], y bf16 [M,512],
 // mean / rstd f32 [M].  K % 128 == 0, K >= 256.
@@ -233,18 +310,31 @@ extern "C" int neat_gemm_bf16_res_ln(const uint16_t* A, const uint16_t* Wp, cons
     NEAT_REQUIRE(res != x_out, NEAT_ERR_ARG, "neat_gemm_bf16_res_ln: res must not alias x_out");
     NEAT_REQUIRE(M > 0 && N == R_N && K >= 2 * R_BKH && K % R_BKH == 0, NEAT_ERR_SHAPE,
                  "neat_gemm_bf16_res_ln: M=%d N=%d K=%d unsupported (N == %d, K %% 128 == 0, K >= 256)", M, N, K, R_N);
-    static unsigned long long attr_done = 0;
-    if (int rc = ensure_dynamic_lds((const void*)gemm_rowln_kernel<2>, R_LDS, &attr_done, "hipFuncSetAttribute(gemm_rowln)"))
-        return rc;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0)
-        cus = 256;
-    const int units = cdiv(M, 64);
-    const int grid = units < 2 * cus ? units : 2 * cus;
-    hipLaunchKernelGGL((gemm_rowln_kernel<2>), dim3(grid), dim3(R_THREADS), R_LDS, (hipStream_t)stream, A,
-                       reinterpret_cast<const uint4*>(Wp), bias, res, gamma, beta, x_out, reinterpret_cast<bf16_t*>(y), mean,
-                       rstd, M, K, eps);
-    NEAT_LAUNCH_CHECK("neat_gemm_bf16_res_ln");
-    return NEAT_OK;
+    return launch_wide<W_LN>(A, Wp, bias, res, gamma, beta, x_out, y, mean, rstd, M, K, eps, (hipStream_t)stream,
+                             "neat_gemm_bf16_res_ln");
 }
+
+// neat_gemm_bf16's N = 512 launches of at most one 128 x 256 unit per CU (see the header comment): called from gemm.hip.
+namespace neat {
+bool gemm_wide512_applies(int M, int N, int K, int epilogue) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("NEAT_GEMM_WIDE512");                // 0: never, 2 / 3: one epilogue only (kernel A/B runs)
+        enabled = e ? atoi(e) : 1;
+    }
+    if (!enabled || N != R_N || K % R_BKH != 0 || K < R_BKH) return false;
+    if (epilogue != NEAT_EPI_BIAS_RES_F32 && epilogue != NEAT_EPI_BF16) return false;
+    if (enabled == 2 && epilogue != NEAT_EPI_BIAS_RES_F32) return false;      // 2: the residual epilogue only
+    if (enabled == 3 && epilogue != NEAT_EPI_BF16) return false;              // 3: the bf16 epilogue only
+    return (long)cdiv(M, 128) * 2 <= wide_cus();
+}
+
+int launch_gemm_wide512(int epilogue, const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, void* out0,
+                        int M, int K, hipStream_t s) {
+    if (epilogue == NEAT_EPI_BIAS_RES_F32)
+        return launch_wide<W_RES>(A, Wp, bias, res, nullptr, nullptr, (float*)out0, nullptr, nullptr, nullptr, M, K, 0.f, s,
+                                  "neat_gemm_bf16(wide, residual)");
+    return launch_wide<W_BF16>(A, Wp, nullptr, nullptr, nullptr, nullptr, nullptr, (uint16_t*)out0, nullptr, nullptr, M, K, 0.f,
+                               s, "neat_gemm_bf16(wide, bf16)");
+}
+}  // namespace neat
