@@ -205,6 +205,13 @@ long neat_coarse_ws_floats(int B, int N);
 int neat_coarse_align(const float* q, const float* pos, const float* neg, const float* G, float* S_out,
                       int32_t* idx_out, float* coarse_out, float* ws, int B, int N, int D, void* stream);
 
+/* Image-to-text coarse alignment, train_TTA.py:20-28 (coarse_aligning_i2t -- defined by the reference and never called
+ * by it; built for the `--tta-retrieval i2t` direction SURVEY 8(f4) lists).  q f32 [B,D] (image queries); G, Gp, Gn f32
+ * [N,D] (caption, positive-caption and negated-caption galleries).  idx_out i32 [B] = argmax_j
+ * (q Gp^T)(1 - sigmoid(q Gn^T)) (first max); coarse_out f32 [B,D] = G[idx].  ws: neat_coarse_ws_floats(B,N) floats. */
+int neat_coarse_align_i2t(const float* q, const float* G, const float* Gp, const float* Gn, int32_t* idx_out,
+                          float* coarse_out, float* ws, int B, int N, int D, void* stream);
+
 /* The same computation with NO workspace argument and NO allocation of any kind (no hipMalloc / hipFree, no allocating
  * library call).  It has no counterpart in the reference: it exists for callers that cannot allocate -- code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-tile partial results live in a 2-MiB

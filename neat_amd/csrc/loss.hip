@@ -324,6 +324,82 @@ __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restric
     }
 }
 
+// The image-to-text form (reference train_TTA.py:20-28, a helper the reference defines and never calls): ONE query, TWO
+// galleries -- A = (q Gp^T)(1 - sigmoid(q Gn^T)) -> per-row (max, first argmax) of this 64-column tile.  Same tiling and
+// exact-fp32 MFMA chains as coarse_tile_kernel; no score matrix is stored (the reference returns the gathered rows only).
+__global__ __launch_bounds__(256) void coarse_i2t_tile_kernel(const float* __restrict__ q, const float* __restrict__ Gp,
+                                                              const float* __restrict__ Gn, float* __restrict__ pval,
+                                                              int* __restrict__ pidx, int B, int N, int D, int ntn) {
+    __shared__ __attribute__((aligned(16))) float Qs[2][SG_SLAB], Ps[2][SG_SLAB], Ns[2][SG_SLAB];
+    __shared__ float rval[2][SG_T];
+    __shared__ int ridx[2][SG_T];
+    const int m0 = blockIdx.y * SG_T, n0 = blockIdx.x * SG_T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 ap, an;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ap[r] = an[r] = 0.0f;
+    const int ns = D / SG_K;
+    float4 rq = sg_fetch<false>(q, B, D, D, m0, 0), rp = sg_fetch<false>(Gp, N, D, D, n0, 0),
+           rn = sg_fetch<false>(Gn, N, D, D, n0, 0);
+    sg_put<false>(Qs[0], rq);
+    sg_put<false>(Ps[0], rp);
+    sg_put<false>(Ns[0], rn);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        if (s + 1 < ns) {
+            const int k0 = (s + 1) * SG_K;
+            rq = sg_fetch<false>(q, B, D, D, m0, k0);
+            rp = sg_fetch<false>(Gp, N, D, D, n0, k0);
+            rn = sg_fetch<false>(Gn, N, D, D, n0, k0);
+        }
+        const int b = s & 1;
+#pragma unroll
+        for (int kk = 0; kk < SG_K / 2; ++kk) {
+            const float a = sg_frag(Qs[b], kk, wm, lane);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sg_frag(Ps[b], kk, wn, lane), ap, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sg_frag(Ns[b], kk, wn, lane), an, 0, 0, 0);
+        }
+        if (s + 1 < ns) {
+            sg_put<false>(Qs[b ^ 1], rq);
+            sg_put<false>(Ps[b ^ 1], rp);
+            sg_put<false>(Ns[b ^ 1], rn);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm + sg_row(r, lane);
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        if (n < N) {
+            const float a = ap[r] * (1.0f - 1.0f / (1.0f + expf(-an[r])));
+            if (a > best) { best = a; bi = n; }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((lane & 31) == 0) { rval[wave & 1][row] = best; ridx[wave & 1][row] = bi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SG_T) {
+        const int m = m0 + threadIdx.x;
+        float best = rval[0][threadIdx.x];
+        int bi = ridx[0][threadIdx.x];
+        const float ov = rval[1][threadIdx.x];
+        const int oi = ridx[1][threadIdx.x];
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if (m < B) {
+            pval[(long)m * ntn + blockIdx.x] = best;
+            pidx[(long)m * ntn + blockIdx.x] = bi;
+        }
+    }
+}
+
 // one wavefront per caption row: (max, first argmax) over the column tiles, then the gallery row is copied out
 __global__ __launch_bounds__(64) void coarse_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
                                                           const float* __restrict__ G, int32_t* __restrict__ idx_out,
@@ -550,6 +626,23 @@ extern "C" int neat_coarse_align(const float* q, const float* pos, const float* 
     NEAT_LAUNCH_CHECK("neat_coarse_align(tile)");
     hipLaunchKernelGGL(coarse_final_kernel, dim3(B), dim3(64), 0, s, pval, pidx, G, idx_out, coarse_out, ntn, D);
     NEAT_LAUNCH_CHECK("neat_coarse_align(final)");
+    return NEAT_OK;
+}
+
+// Image-to-text coarse alignment (reference train_TTA.py:20-28): idx = argmax_j (q Gp^T)(1 - sigmoid(q Gn^T)) (first max),
+// coarse_out = G[idx].  q f32 [B,D]; G, Gp, Gn f32 [N,D]; ws as for neat_coarse_align.
+extern "C" int neat_coarse_align_i2t(const float* q, const float* G, const float* Gp, const float* Gn, int32_t* idx_out,
+                                     float* coarse_out, float* ws, int B, int N, int D, void* stream) {
+    NEAT_REQUIRE(q && G && Gp && Gn && idx_out && coarse_out && ws, NEAT_ERR_ARG, "neat_coarse_align_i2t: null pointer");
+    NEAT_REQUIRE(B > 0 && N > 0 && D > 0 && D % SG_K == 0, NEAT_ERR_SHAPE, "neat_coarse_align_i2t: D=%d must be a multiple of 16", D);
+    const int ntn = cdiv(N, SG_T);
+    float* pval = ws;
+    int* pidx = reinterpret_cast<int*>(ws + (long)B * ntn);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(coarse_i2t_tile_kernel, dim3(ntn, cdiv(B, SG_T)), dim3(256), 0, s, q, Gp, Gn, pval, pidx, B, N, D, ntn);
+    NEAT_LAUNCH_CHECK("neat_coarse_align_i2t(tile)");
+    hipLaunchKernelGGL(coarse_final_kernel, dim3(B), dim3(64), 0, s, pval, pidx, G, idx_out, coarse_out, ntn, D);
+    NEAT_LAUNCH_CHECK("neat_coarse_align_i2t(final)");
     return NEAT_OK;
 }
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "neat_frame_mean_norm": (_I, [_P, _P, _I, _I, _I, _P]),
     "neat_coarse_ws_floats": (_L, [_I, _I]),
     "neat_coarse_align": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "neat_coarse_align_i2t": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "neat_coarse_static_max_slots": (_L, []),
     "neat_coarse_static_init": (_I, []),
     "neat_coarse_align_static": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

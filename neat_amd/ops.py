@@ -457,6 +457,22 @@ def coarse_align(q, pos, neg, G):
     return coarse, idx, S
 
 
+def coarse_align_i2t(q, G, Gp, Gn):
+    """neat_coarse_align_i2t (reference train_TTA.py:20-28): q f32 [B,D]; G, Gp, Gn f32 [N,D] ->
+    (G[idx] f32 [B,D], idx int32 [B]) with idx = argmax_j (q Gp^T)(1 - sigmoid(q Gn^T))."""
+    B, D = q.shape
+    N = G.shape[0]
+    if tuple(Gp.shape) != (N, D) or tuple(Gn.shape) != (N, D) or G.shape[1] != D:
+        raise RuntimeError("coarse_align_i2t: G, Gp, Gn must all be [N, D] with q's D")
+    dev = q.device
+    idx = torch.empty(B, dtype=i32, device=dev)
+    coarse = torch.empty(B, D, dtype=f32, device=dev)
+    ws = torch.empty(lib.load().neat_coarse_ws_floats(B, N), dtype=f32, device=dev)
+    lib.call("neat_coarse_align_i2t", _p(q, f32, "q"), _p(G, f32, "G"), _p(Gp, f32, "Gp"), _p(Gn, f32, "Gn"), _p(idx),
+             _p(coarse), _p(ws), B, N, D, _stream())
+    return coarse, idx
+
+
 def coarse_align_static(q, pos, neg, G, S, idx, coarse):
     """neat_coarse_align_static: the caller passes every output; the call allocates nothing (the per-tile partials live
     in the library's static device array; B * ceil(N/64) <= neat_coarse_static_max_slots())."""

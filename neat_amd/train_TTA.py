@@ -43,6 +43,15 @@ def coarse_aligning_t2i(query_feat, pos_query_feat, neg_query_feat, gallery_feat
     return coarse, idx.long(), None, ops.topk_rows(S, 1)[1][:, 0].long(), S
 
 
+@torch.no_grad()
+def coarse_aligning_i2t(query_feat, gallery_feat_all, pos_gallery_feat_all, neg_gallery_feat_all):
+    """train_TTA.py:20-28: the image-to-text direction (image queries against caption / positive-caption / negated-caption
+    galleries, sigmoid instead of relu).  The reference defines this helper and never calls it (its ``tta_only_visual``
+    branch is ``pass``, :113-114); it is provided with the reference's signature and return value (the gathered rows)."""
+    return ops.coarse_align_i2t(query_feat.detach().contiguous(), gallery_feat_all.contiguous(),
+                                pos_gallery_feat_all.contiguous(), neg_gallery_feat_all.contiguous())[0]
+
+
 def tta_loss(text_feat, pos_text_feat, inv_text_feat, coarse_img_feat, T1, T2):
     """loss_entropy, loss_sr, loss_tri (train_TTA.py:138-143) and their gradients, no autograd."""
     return ops.tta_loss_fwd_bwd(text_feat, pos_text_feat, inv_text_feat, text_feat, coarse_img_feat, T1, T2, 0)

@@ -246,6 +246,14 @@ def coarse_align_t2i(t, p, n, G):
     return G[idx], idx, S
 
 
+def coarse_align_i2t(q, G, Gp, Gn):
+    """train_TTA.py:20-28 (coarse_aligning_i2t; the reference defines it and never calls it).  q [B,D] image queries;
+    G, Gp, Gn [N,D] caption / positive-caption / negated-caption galleries.  Returns (G[idx] [B,D], idx [B])."""
+    A = (q @ Gp.t()) * (1.0 - torch.sigmoid(q @ Gn.t()))
+    idx = A.argmax(dim=1)
+    return G[idx], idx
+
+
 def tta_loss_fwd_bwd(t, p, v, c, T1: float, T2: float):
     """loss_entropy + loss_sr + loss_tri and its gradient w.r.t. t, p, v (c carries no grad).
 

@@ -311,6 +311,26 @@ def case_loss_ties(tt):
     print("loss_ties", le.item(), ls.item(), lt.item(), "distinct coarse", len(set(idx.tolist())))
 
 
+def case_coarse_i2t(tt):
+    """The reference's image-to-text coarse alignment (train_TTA.py:20-28, defined there and never called) on seeded unit
+    features: B = 70 image queries against N = 333 caption rows (ragged against the kernels' 64-wide tiles), D = 64."""
+    g = torch.Generator().manual_seed(23)
+    B, N, D = 70, 333, 64
+    norm = torch.nn.functional.normalize
+    q = norm(torch.randn(B, D, generator=g), dim=-1)
+    G = norm(torch.randn(N, D, generator=g), dim=-1)
+    Gp = norm(G + 0.5 * torch.randn(N, D, generator=g), dim=-1)
+    Gn = norm(torch.randn(N, D, generator=g), dim=-1)
+    out = tt.coarse_aligning_i2t(q, G, Gp, Gn)
+    A = (q @ Gp.t()) * (1 - torch.sigmoid(q @ Gn.t()))
+    idx = A.argmax(dim=1)
+    assert torch.equal(out, G[idx])                               # the function returns the gathered rows only
+    top2 = A.topk(2, dim=1).values
+    np.savez_compressed(os.path.join(HERE, "coarse_i2t.npz"), q=q.numpy(), G=G.numpy(), Gp=Gp.numpy(), Gn=Gn.numpy(),
+                        out=out.numpy(), idx=idx.numpy().astype(np.int32), margin=(top2[:, 0] - top2[:, 1]).numpy())
+    print("coarse_i2t distinct", len(set(idx.tolist())), "min margin", float((top2[:, 0] - top2[:, 1]).min()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", default=["recall", "loss_ties", "tiny", "vitb32_b32"])
@@ -323,6 +343,8 @@ def main():
             case_recall(retrieval)
         elif c == "loss_ties":
             case_loss_ties(tt)
+        elif c == "coarse_i2t":
+            case_coarse_i2t(tt)
         elif c == "tiny":
             case_tta(oc, tt, retrieval, "tiny", "neat-tiny", n_text=40, n_image=24, bs_text=16, bs_image=10)
         elif c == "vitb32_b32":

@@ -451,6 +451,37 @@ def test_coarse_align_ties_pick_first():
     assert (idx.cpu() < 5).all()
 
 
+def test_coarse_align_i2t_vs_reference_fixture_and_oracle():
+    """neat_coarse_align_i2t (reference train_TTA.py:20-28) against the reference function's own output on the committed
+    fixture -- index-exact on every row whose top-2 margin exceeds fp32 summation-order noise (1e-5; the fixture's tightest
+    margin is 1.4e-6) -- and against the oracle at sizes ragged against the 64-wide tiles, through the reference-named
+    wrapper as well."""
+    from neat_amd import train_TTA as T
+    z = load_golden("coarse_i2t")
+    q, G, Gp, Gn = (torch.from_numpy(z[k]).to(DEV) for k in ("q", "G", "Gp", "Gn"))
+    out, idx = ops.coarse_align_i2t(q, G, Gp, Gn)
+    sure = z["margin"] > 1e-5
+    assert sure.sum() >= 60
+    assert np.array_equal(idx.cpu().numpy()[sure], z["idx"][sure])
+    assert np.array_equal(out.cpu().numpy()[sure], z["out"][sure])
+    assert torch.equal(out, G[idx.long()])
+    assert torch.equal(T.coarse_aligning_i2t(q, G, Gp, Gn), out)
+    for B, N, D, seed in ((1, 1, 16, 1), (257, 5000, 512, 2), (64, 64, 768, 3), (130, 77, 32, 4)):
+        q, G, Gp, Gn = _unit(B, D, seed), _unit(N, D, seed + 10), _unit(N, D, seed + 20), _unit(N, D, seed + 30)
+        ref_out, ref_idx = O.coarse_align_i2t(q, G, Gp, Gn)
+        A = (q @ Gp.t()) * (1 - torch.sigmoid(q @ Gn.t()))
+        out, idx = ops.coarse_align_i2t(q.to(DEV), G.to(DEV), Gp.to(DEV), Gn.to(DEV))
+        idx = idx.cpu().long()
+        # the chosen column's score is the row maximum up to summation order; where the margin is clear the index is equal
+        assert (A.gather(1, idx[:, None])[:, 0] >= A.max(dim=1).values - 1e-5).all()
+        top2 = A.topk(min(2, N), dim=1).values
+        clear = (top2[:, 0] - top2[:, -1] > 1e-5) if N > 1 else torch.ones(B, dtype=torch.bool)
+        assert torch.equal(idx[clear], ref_idx[clear])
+        assert torch.equal(out.cpu(), G[idx])
+    with pytest.raises(RuntimeError):
+        ops.coarse_align_i2t(_unit(4, 24, 1).to(DEV), _unit(5, 24, 2).to(DEV), _unit(5, 24, 3).to(DEV), _unit(5, 24, 4).to(DEV))
+
+
 def test_loss_fwd_bwd_golden_ties():
     """Inputs and expected values produced by the REFERENCE functions + autograd (tests/golden/loss_ties.npz)."""
     z = load_golden("loss_ties")
