@@ -59,7 +59,20 @@ class KernelTimer:
         return sum(ms) / len(ms), sum(fl) / len(fl), len(ms)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The raw handle of torch's current stream on the current device.  Every library call passes it, ~530 times per
+    adaptation batch: torch.cuda.current_stream() builds a Stream object behind several availability checks (8 us per call,
+    a third of the host time of a packed step under cProfile, tools/host_enqueue_probe.py); the two C accessors it ends in
+    are called directly when this torch has them."""
+    if _raw_stream is not None and _cur_device is not None:
+        try:
+            return _raw_stream(_cur_device())
+        except RuntimeError:                      # before torch has initialised the GPU: take the slow, initialising path
+            pass
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -26,6 +26,7 @@ from typing import Optional
 
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -207,13 +208,35 @@ def _ln_grad_views(model):
     return grads
 
 
-def batch_plan(model, tokens4):
+def host_cu_seqlens(host_tokens4):
+    """The packed layout from tokens still on the HOST: int32 [4*Bl + 1] prefix sums of (EOT position + 1) over the rows of
+    [text, pos, inv, neg]; EOT = the first maximum of a row (reference open_clip/transformer.py:555-558, the same rule as
+    the library's neat_pack_plan; ``numpy.argmax`` returns the first maximum)."""
+    text, pos, neg, inv = host_tokens4
+    cat = torch.cat([text, pos, inv, neg], dim=0).numpy()
+    cu = np.zeros(cat.shape[0] + 1, dtype=np.int32)
+    np.cumsum(cat.argmax(axis=1) + 1, out=cu[1:])
+    return torch.from_numpy(cu)
+
+
+def batch_plan(model, tokens4, host_tokens4=None):
     """What the tta_steps of ONE adaptation batch share: the four token sets as one [4*Bl, L] batch ordered
-    [text, pos, inv, neg] and, with packed text batches, its packed layout (one small device-to-host copy).  Pass the
-    result to every ``tta_step(..., plan=)`` of the batch."""
+    [text, pos, inv, neg] and, with packed text batches, its packed layout.  Pass the result to every
+    ``tta_step(..., plan=)`` of the batch.
+
+    The layout (cu_seqlens) is needed on the device AND on the host (its totals size the step's buffers).  When the
+    caller still holds the tokens on the host (``host_tokens4``: the same rows as ``tokens4``, CPU int64 -- what
+    ``train_one_epoch`` has right after tokenising), it is computed there and sent to the device with a pinned,
+    non-blocking copy: no device-to-host copy, so the host does not wait for the previous batch's kernels.  Otherwise the
+    library computes it from the device tokens and one small device-to-host copy brings it back."""
     text, pos, neg, inv = tokens4
     toks = torch.cat([text, pos, inv, neg], dim=0)
     if bool(getattr(model, "pack_tokens", False)) and toks.is_cuda:
+        if host_tokens4 is not None:
+            cu_host = host_cu_seqlens(host_tokens4)
+            if cu_host.numel() != toks.shape[0] + 1:
+                raise RuntimeError("batch_plan: host_tokens4 does not hold the rows of tokens4")
+            return toks.contiguous(), cu_host.pin_memory().to(toks.device, non_blocking=True), cu_host
         return model._text_tower().plan(toks)
     return (toks, None, None)
 
@@ -339,6 +362,8 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     # non-blocking copy (a pageable copy is ordered behind the previous batch's kernels and blocks the host until they
     # are done), and a batch's losses are logged after the NEXT batch has been enqueued (same lines, same order as the
     # reference's per-batch `.item()` at train_TTA.py:148).  Tokenising batch i+1 then runs under the GPU time of batch i.
+    # With packed text batches the layout of a batch is computed from the HOST tokens (batch_plan) for the same reason: the
+    # library's plan needs a device-to-host copy, which is ordered behind everything enqueued before it.
     def _h2d(x):
         if x.is_cuda or torch.device(device).type != "cuda":
             return x.to(device)
@@ -367,7 +392,8 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
     for text, pos_text, neg_text, inv_text, idx in data_loader_text:
         toks = [tokenizer(x) for x in (text, pos_text, neg_text, inv_text)]
         toks = [x if x.dtype == torch.int64 else x.long() for x in toks]
-        if all(not x.is_cuda for x in toks) and len({tuple(x.shape) for x in toks}) == 1:
+        host_toks = toks if all(not x.is_cuda for x in toks) else None       # kept for the packed plan (batch_plan)
+        if host_toks is not None and len({tuple(x.shape) for x in toks}) == 1:
             toks = list(_h2d(torch.stack(toks)).unbind(0))
         else:
             toks = [_h2d(x) for x in toks]
@@ -386,7 +412,9 @@ def train_one_epoch(model, tokenizer, data_loader_text, data_loader_image, optim
                 raise RuntimeError(f"train_one_epoch: a batch of {Bt} caption rows cannot be cut over {world} ranks")
             lo, hi = _shard(Bt, world, rank)
             local = [x[lo:hi].contiguous() for x in toks]
-        plan = batch_plan(clip, local)
+            if host_toks is not None:
+                host_toks = [x[lo:hi] for x in host_toks]
+        plan = batch_plan(clip, local, host_toks)
         for _ in range(args.tta_steps):
             losses, _, sims = tta_step(clip, optimizer, local, all_image_embeds, T1, T2, world, rank, global_rows=Bt,
                                        plan=plan)

@@ -654,6 +654,47 @@ def test_packed_tokens_equal_full_length(name, B):
     assert rel_l2(b["p"], a["p"]) < 1e-6
 
 
+def test_batch_plan_from_host_tokens_equals_the_device_plan():
+    """train_one_epoch computes the packed layout from the tokens it still holds on the host (no device-to-host copy, so
+    the host does not wait for the previous batch): the same cu_seqlens as the library's neat_pack_plan on the device
+    tokens -- rows with a repeated maximum (first one wins), a row that is all zeros, a sharded slice -- and a step run
+    with either plan gives bit-identical results."""
+    name = "neat-tiny"
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    host = list(synth.synth_caption_sets(11, t["context_length"], t["vocab_size"], 77))
+    host[0] = host[0].clone()
+    host[0][2, 5] = host[0][2].max()                    # the maximum twice in one row: EOT = its first position
+    host[0][2, 1] = host[0][2].max()
+    host[1] = host[1].clone()
+    host[1][4] = 0                                      # all equal: position 0
+    model, _ = _model(name, 0)
+    model.pack_tokens = True
+    for lo, hi in ((0, 11), (3, 8)):
+        h = [x[lo:hi] for x in host]
+        d = [x.to(DEV) for x in h]
+        p_dev = T.batch_plan(model, d)
+        p_host = T.batch_plan(model, d, h)
+        assert torch.equal(p_dev[0], p_host[0])
+        assert torch.equal(p_dev[1], p_host[1]) and p_host[1].dtype == torch.int32 and p_host[1].is_cuda
+        assert torch.equal(p_dev[2], p_host[2]) and not p_host[2].is_cuda
+    with pytest.raises(RuntimeError):
+        T.batch_plan(model, d, [x[:2] for x in h])
+    G = torch.nn.functional.normalize(torch.randn(9, cfg["embed_dim"], generator=torch.Generator().manual_seed(2)), dim=-1).to(DEV)
+    res = []
+    for use_host in (False, True):
+        model, _ = _model(name, 0)
+        model.pack_tokens = True
+        oc.freeze_parameters(model, False)
+        opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+        d = [x.to(DEV) for x in host]
+        plan = T.batch_plan(model, d, host if use_host else None)
+        losses, idx, S = T.tta_step(model, opt, d, G, 0.03, 0.07, plan=plan)
+        res.append((losses.cpu(), idx.cpu(), S.cpu(), _flat_ln(model)))
+    for a, b in zip(*res):
+        assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+
+
 class _ListLoader:
     def __init__(self, batches, n):
         self.batches, self.dataset = batches, list(range(n))

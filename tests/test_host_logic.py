@@ -219,6 +219,24 @@ def _run_bench(*argv, env_extra=None):
                           timeout=240)
 
 
+def test_host_cu_seqlens_is_the_prefix_sum_of_first_argmax_plus_one():
+    """train_TTA.host_cu_seqlens (the packed layout from host tokens): rows ordered [text, pos, inv, neg], EOT = first
+    maximum of a row (torch.argmax on the reference's side, open_clip/transformer.py:555-558)."""
+    from neat_amd import train_TTA as T
+    g = torch.Generator().manual_seed(3)
+    sets = [torch.randint(0, 50, (7, 13), generator=g) for _ in range(4)]
+    sets[0][1, 3] = sets[0][1, 9] = 99                  # a tie: the first position counts
+    sets[3][0] = 0
+    text, pos, neg, inv = sets
+    cu = T.host_cu_seqlens((text, pos, neg, inv))
+    cat = torch.cat([text, pos, inv, neg])
+    want = [0]
+    for row in cat.tolist():
+        want.append(want[-1] + row.index(max(row)) + 1)
+    assert cu.dtype == torch.int32 and cu.tolist() == want
+    assert cu[2] - cu[1] == 4 and cu[15] - cu[14] == 1       # inv (the 4th argument) is the 3rd block of rows
+
+
 def test_bench_gpus_n_launches_n_ranks_itself():
     """`python bench.py --gpus 2` with no launcher around it: two ranks under torch.distributed.run, rank 0's one JSON
     line relayed, the child's status returned (reference intent: main_TTA.py:245-256, one process per GPU)."""

@@ -38,3 +38,17 @@ for packed in (False, True):
     t2 = time.perf_counter()
     print(f"packed={packed}: host enqueue {(t1 - t0) / nb * 1e3:.2f} ms per batch, wall {(t2 - t0) / nb * 1e3:.2f} ms per batch "
           f"({(t2 - t0) / nb / 3 * 1e3:.2f} ms per step)", flush=True)
+
+if os.environ.get("PROFILE"):
+    # where the host time of the packed step goes (cProfile inflates everything ~2x; read the ranking, not the numbers)
+    import cProfile, pstats
+    model.pack_tokens = True
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(nb):
+        run(i)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
