@@ -271,6 +271,195 @@ __global__ __launch_bounds__(R_THREADS, 4) void gemm_rowln_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the same 64 x 512 unit with the K loop cut in two INSIDE the workgroup -------------------------------------------
+// The launches this file serves put at most ONE unit on a CU (packed text batches, the MCQ scorer): eight waves, two per
+// SIMD, and a main loop that waits out L2 latency with nothing else to run.  Here a workgroup has SIXTEEN waves: waves
+// 0..7 (k-half 0) run k in [0, K/2), waves 8..15 (k-half 1) run [K/2, K), each half with its own double-buffered LDS
+// pieces, the same column split (wave & 7 owns 64 columns) and the same per-wave code as gemm_rowln_kernel -- four waves
+// per SIMD instead of two.  At the end of a unit the halves are added through LDS in two rounds (a wave sends two of its
+// four row tiles each way, 64 KiB per round): k-half 0 ends up with the finished row tiles 0..1, k-half 1 with 2..3, both
+// as (bias + half 0) + half 1 (fp32 addition commutes, so the two directions agree bit for bit; the result differs from
+// the unsplit kernels' single k chain in the last bit), and each half runs the epilogue of its two row tiles.  No
+// workspace, no second launch, no cross-workgroup synchronisation.  K % 256 == 0, K >= 512.
+constexpr int S_THREADS = 1024;
+constexpr int S_EXCH = 4 * R_PIECE;             // 64 KiB of pieces (2 k-halves x 2 buffers), then the exchange region
+constexpr int S_LDS = S_EXCH + 2 * 32768;       // 128 KiB; the bf16 epilogue's wave-private slabs alias the exchange region
+
+template <int MODE>
+__global__ __launch_bounds__(S_THREADS) void gemm_wide_split_kernel(
+    const bf16_t* __restrict__ A, const uint4* __restrict__ Wp, const float* __restrict__ bias, const float* res,
+    float* xout, bf16_t* __restrict__ y, int M, int K, int warm) {
+    static_assert(MODE == W_RES || MODE == W_BF16, "the split kernel has the plain epilogues only");
+    static_assert(R_RT == 4 && R_NI == 4, "the exchange below is written for 4 x 4 accumulator tiles");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int N = R_N;
+    constexpr int ksteps = R_BKH >> 5;
+    constexpr int cpr = R_BKH >> 3;
+    constexpr int rpi = 64 / cpr;
+    constexpr int ninstr = 64 * cpr / 64;
+    constexpr int rowbytes = cpr * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = wave >> 3, w = wave & 7;                          // k-half, column group
+    const int fr = lane & 15, fq = lane >> 4;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int nsub = (M + 63) >> 6;
+    const int G = gridDim.x;
+    const int myunits = (nsub - (int)blockIdx.x + G - 1) / G;
+    if (myunits <= 0) return;
+    const int nkh = (K >> 1) / R_BKH;                                // pieces per k-half
+    const int ksK = K >> 5;
+    const int J = myunits * nkh;
+
+    auto issue_piece = [&](int j) {
+        const int t = j / nkh;
+        const int kh = j - t * nkh;
+        const int row0 = ((int)blockIdx.x + t * G) << 6;
+        const uint32_t buf = lds_base + (g * 2 + (j & 1)) * R_PIECE;
+        const bf16_t* src = A + (g * nkh + kh) * R_BKH;
+        for (int q = (w & 3); q < ninstr; q += 4) {
+            const int row = q * rpi + lane / cpr;
+            const int c = (lane % cpr) ^ (row & 15);
+            int gr = row0 + row;
+            gr = gr < M ? gr : M - 1;
+            rglds16(src + (long)gr * K + c * 8, buf + q * 1024);
+        }
+    };
+
+    typedef unsigned warm_u32x4 __attribute__((ext_vector_type(4)));
+    warm_u32x4 warmv = {0u, 0u, 0u, 0u};
+    if (warm) {
+        const int xcd = blockIdx.x & 7;
+        const long wg = blockIdx.x >> 3, WX = (G - xcd + 7) >> 3;
+        const long wbytes = (long)N * K * 2;
+        const char* wbase = reinterpret_cast<const char*>(Wp);
+        for (long off = (wg * S_THREADS + threadIdx.x) * 16; off < wbytes; off += WX * S_THREADS * 16)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(warmv) : "v"(wbase + off) : "memory");
+    }
+    if ((w >> 2) == 0) issue_piece(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("; warm-up retired" :: "v"(warmv));
+
+    const int nt0 = w * R_NI;
+    f32x4 acc[R_NI][R_RT];
+    for (int j = 0; j < J; ++j) {
+        const int tu = j / nkh;
+        const int kh = j - tu * nkh;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (j + 1 < J && (w >> 2) == ((j + 1) & 1)) issue_piece(j + 1);
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) {
+                f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE != W_BF16) {
+                    if (g == 0) b0 = *reinterpret_cast<const f32x4*>(bias + (nt0 + i) * 16 + fq * 4);
+                }
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) acc[i][t] = b0;
+            }
+        }
+        {
+            const char* abase = lds + (g * 2 + (j & 1)) * R_PIECE + fr * rowbytes;
+            const uint4* wp = Wp + ((long)nt0 * ksK + (long)(g * nkh + kh) * ksteps) * 64 + lane;
+            uint4 wn[R_NI];
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) wn[i] = wp[(long)i * ksK * 64];
+#pragma unroll
+            for (int kk = 0; kk < ksteps; ++kk) {
+                bf16x8 wf[R_NI];
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) wf[i] = __builtin_bit_cast(bf16x8, wn[i]);
+                if (kk + 1 < ksteps) {
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i) wn[i] = wp[(long)i * ksK * 64 + (kk + 1) * 64];
+                }
+                const int coff = ((kk * 4 + fq) ^ fr) * 16;
+                bf16x8 af[R_RT];
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t) af[t] = *reinterpret_cast<const bf16x8*>(abase + t * 16 * rowbytes + coff);
+#pragma unroll
+                for (int t = 0; t < R_RT; ++t)
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[t], acc[i][t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kh != nkh - 1) continue;
+
+        // ---- the two k-halves meet: round r moves row tile 2 + r of half 0 and row tile r of half 1 ----
+        // wave (g, w) writes 4 KiB (its 4 column tiles of one row tile, lane-linear) into its group's 32-KiB area and
+        // reads the partner wave's (1 - g, w).  The exchange region was last touched by the previous unit's epilogue slabs,
+        // at least two piece barriers ago.
+        char* mine = lds + S_EXCH + g * 32768 + (w * 4 * 64 + lane) * 16;
+        const char* theirs = lds + S_EXCH + (1 - g) * 32768 + (w * 4 * 64 + lane) * 16;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) *reinterpret_cast<f32x4*>(mine + i * 1024) = acc[i][2 + r];
+            } else {
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) *reinterpret_cast<f32x4*>(mine + i * 1024) = acc[i][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) acc[i][r] += *reinterpret_cast<const f32x4*>(theirs + i * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) acc[i][2 + r] += *reinterpret_cast<const f32x4*>(theirs + i * 1024);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // read before the next round / the slabs overwrite it
+        }
+        if (g == 1) {
+#pragma unroll
+            for (int i = 0; i < R_NI; ++i) {
+                acc[i][0] = acc[i][2];
+                acc[i][1] = acc[i][3];
+            }
+        }
+        // this wave now holds the finished row tiles 2 g + {0, 1} of its 64 columns in acc[.][0..1]
+        const int row0 = (((int)blockIdx.x + tu * G) << 6) + g * 32;
+        if constexpr (MODE == W_BF16) {
+            char* slab = lds + S_EXCH + wave * 2048;
+            const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int i = 0; i < R_NI; ++i) {
+                    const f32x4 v = acc[i][t];
+                    char* p = slab + fr * 128 + (((2 * i + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8;
+                    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rrow = rr + 8 * h;
+                    const uint4 q = *reinterpret_cast<const uint4*>(slab + rrow * 128 + ((cc ^ (rrow & 7)) << 4));
+                    const int m = row0 + t * 16 + rrow;
+                    if (m < M) *reinterpret_cast<uint4*>(y + (long)m * N + w * 64 + cc * 8) = q;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = row0 + t * 16 + fr;
+                if (m < M) {
+#pragma unroll
+                    for (int i = 0; i < R_NI; ++i) {
+                        const long o = (long)m * N + w * 64 + i * 16 + fq * 4;
+                        const float4 rv = *reinterpret_cast<const float4*>(res + o);
+                        const f32x4 v = acc[i][t];
+                        *reinterpret_cast<float4*>(xout + o) = make_float4(v[0] + rv.x, v[1] + rv.y, v[2] + rv.z, v[3] + rv.w);
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace neat
 
 using namespace neat;
@@ -314,6 +503,23 @@ extern "C" int neat_gemm_bf16_res_ln(const uint16_t* A, const uint16_t* Wp, cons
                              "neat_gemm_bf16_res_ln");
 }
 
+template <int MODE>
+static int launch_wide_split(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, float* x_out,
+                             uint16_t* y, int M, int K, hipStream_t s, const char* what) {
+    static unsigned long long attr_done = 0;
+    if (int rc = ensure_dynamic_lds((const void*)gemm_wide_split_kernel<MODE>, S_LDS, &attr_done,
+                                    "hipFuncSetAttribute(gemm_wide_split)"))
+        return rc;
+    const int cus = wide_cus();
+    const int units = cdiv(M, 64);
+    const int grid = units < cus ? units : cus;                      // one 16-wave workgroup per CU
+    hipLaunchKernelGGL((gemm_wide_split_kernel<MODE>), dim3(grid), dim3(S_THREADS), S_LDS, s, A,
+                       reinterpret_cast<const uint4*>(Wp), bias, res, x_out, reinterpret_cast<bf16_t*>(y), M, K,
+                       gemm_warm_w_enabled());
+    NEAT_LAUNCH_CHECK(what);
+    return NEAT_OK;
+}
+
 // neat_gemm_bf16's N = 512 launches of at most one 128 x 256 unit per CU (see the header comment): called from gemm.hip.
 namespace neat {
 bool gemm_wide512_applies(int M, int N, int K, int epilogue) {
@@ -331,6 +537,16 @@ bool gemm_wide512_applies(int M, int N, int K, int epilogue) {
 
 int launch_gemm_wide512(int epilogue, const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res, void* out0,
                         int M, int K, hipStream_t s) {
+    static int split = -1;
+    if (split < 0) {
+        const char* e = getenv("NEAT_GEMM_WIDE_SPLIT");              // 0: the unsplit 8-wave kernel (A/B runs)
+        split = e ? atoi(e) : 1;
+    }
+    if (split && K % (2 * R_BKH) == 0 && K >= 4 * R_BKH && cdiv(M, 64) <= wide_cus()) {
+        if (epilogue == NEAT_EPI_BIAS_RES_F32)
+            return launch_wide_split<W_RES>(A, Wp, bias, res, (float*)out0, nullptr, M, K, s, "neat_gemm_bf16(wide split, residual)");
+        return launch_wide_split<W_BF16>(A, Wp, nullptr, nullptr, nullptr, (uint16_t*)out0, M, K, s, "neat_gemm_bf16(wide split, bf16)");
+    }
     if (epilogue == NEAT_EPI_BIAS_RES_F32)
         return launch_wide<W_RES>(A, Wp, bias, res, nullptr, nullptr, (float*)out0, nullptr, nullptr, nullptr, M, K, 0.f, s,
                                   "neat_gemm_bf16(wide, residual)");

@@ -146,7 +146,7 @@ def test_gemm_epilogues(M, N, K, kern):
 @pytest.mark.parametrize("M,K", [(64 * 37 + 5, 256), (14848, 512), (1000, 2048), (40000, 512)])
 def test_gemm_res_ln_equals_gemm_then_layernorm(M, K):
     """neat_gemm_bf16_res_ln (residual GEMM + the LayerNorm that follows it, one launch, 64 x 512 units) against the two
-    launches it replaces: x_out bit-identical to the panel kernel's BIAS_RES_F32 result (same MFMA order per output), the
+    launches it replaces: x_out bit-identical to neat_gemm_bf16's BIAS_RES_F32 result where that is one k chain too, the
     statistics and y = LN(x_out) equal to neat_ln_fwd on that x_out up to the summation order of the row reductions (a
     bf16 value may land on the neighbouring grid point), and both against the fp32 reference."""
     N = 512
@@ -159,7 +159,12 @@ def test_gemm_res_ln_equals_gemm_then_layernorm(M, K):
     Ad, Wd = A.to(DEV), ops.pack_weight(W.float().to(DEV))
     x, y, mu, rs = ops.gemm_res_ln(Ad, Wd, bias.to(DEV), res.to(DEV), gam.to(DEV), bet.to(DEV))
     x2, _ = ops.gemm(Ad, Wd, lib.EPI_BIAS_RES_F32, bias=bias.to(DEV), res=res.to(DEV), kernel="panel")
-    assert torch.equal(x, x2)
+    if M <= 16384 and K >= 512 and K % 256 == 0:
+        # neat_gemm_bf16 runs this shape on the 16-wave split-K form of the 64 x 512 unit: (bias + k-half 0) + k-half 1
+        # instead of one k chain, equal up to the last bit of an fp32 sum
+        assert rel_l2(x.cpu(), x2.cpu()) < 2e-7 and float((x - x2).abs().max()) < 4e-6
+    else:
+        assert torch.equal(x, x2)
     y2, _, mu2, rs2 = ops.ln_fwd(x2, gam.to(DEV), bet.to(DEV))
     assert rel_l2(mu.cpu(), mu2.cpu()) < 1e-5 and rel_l2(rs.cpu(), rs2.cpu()) < 1e-6
     d = (y.float() - y2.float()).abs()

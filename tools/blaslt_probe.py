@@ -1,10 +1,12 @@
 """Vendor-library yardstick: torch.mm (hipBLASLt / rocBLAS) on the eight GEMM shapes of one text layer, plain bf16 out.
 Not part of the product path; prints us per launch."""
+import os
 import torch
 dev = "cuda"
+M4, M3 = int(os.environ.get("M4", 78848)), int(os.environ.get("M3", 59136))     # forward / backward rows (packed: 14848 / 11136)
 g = torch.Generator(device=dev).manual_seed(0)
-shapes = [("qkv", 78848, 1536, 512), ("out", 78848, 512, 512), ("fc", 78848, 2048, 512), ("proj", 78848, 512, 2048),
-          ("dproj", 59136, 2048, 512), ("dfc", 59136, 512, 2048), ("do", 59136, 512, 512), ("dqkv", 59136, 512, 1536)]
+shapes = [("qkv", M4, 1536, 512), ("out", M4, 512, 512), ("fc", M4, 2048, 512), ("proj", M4, 512, 2048),
+          ("dproj", M3, 2048, 512), ("dfc", M3, 512, 2048), ("do", M3, 512, 512), ("dqkv", M3, 512, 1536)]
 tot = 0.0
 for name, M, N, K in shapes:
     A = torch.randn(M, K, generator=g, device=dev).bfloat16()
