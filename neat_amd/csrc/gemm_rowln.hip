@@ -26,6 +26,7 @@
 // that is what the weight warm-up at kernel start buys (see gemm_panel_kernel): with it the packed step gains 2.9 %
 // (15.08 -> 14.65 ms per batch of 256, tools/experiments/wide_ab.sh); without it the same dispatch was neutral.  At 78 848
 // rows the panel kernel's longer weight reuse wins (104.8 vs 131.6 us) and keeps those launches.
+// Those launches run the 16-wave split-K form of the unit (gemm_wide_split_kernel below) when K % 256 == 0, K >= 512.
 #include <stdlib.h>
 
 #include "common.h"
