@@ -1019,5 +1019,10 @@ extern "C" int neat_gemm_prefers_t256(int M, int N, int K, int epilogue) {
     const long units = (long)cdiv(M, 256) * (N / 256);
     const int cus = num_cus();
     const long rounds = (units + cus - 1) / cus;
-    return units * 2 >= 3L * cus && units * 4 >= 3 * rounds * cus;
+    static int min_fill_x2 = -1;                // NEAT_GEMM_T256_MIN_FILL_X2 (experiments): units * 2 >= this * CUs; default 3
+    if (min_fill_x2 < 0) {
+        const char* e = getenv("NEAT_GEMM_T256_MIN_FILL_X2");
+        min_fill_x2 = e ? atoi(e) : 3;
+    }
+    return units * 2 >= (long)min_fill_x2 * cus && units * 4 >= 3 * rounds * cus;
 }

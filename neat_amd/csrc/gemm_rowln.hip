@@ -533,6 +533,12 @@ bool gemm_wide512_applies(int M, int N, int K, int epilogue) {
     if (epilogue != NEAT_EPI_BIAS_RES_F32 && epilogue != NEAT_EPI_BF16) return false;
     if (enabled == 2 && epilogue != NEAT_EPI_BIAS_RES_F32) return false;      // 2: the residual epilogue only
     if (enabled == 3 && epilogue != NEAT_EPI_BF16) return false;              // 3: the bf16 epilogue only
+    static long maxrows = -1;                                       // NEAT_GEMM_WIDE_MAXROWS (experiments): row limit instead of one unit per CU
+    if (maxrows < 0) {
+        const char* e = getenv("NEAT_GEMM_WIDE_MAXROWS");
+        maxrows = e ? atol(e) : 0;
+    }
+    if (maxrows > 0) return M <= maxrows;
     return (long)cdiv(M, 128) * 2 <= wide_cus();
 }
 
@@ -543,7 +549,7 @@ int launch_gemm_wide512(int epilogue, const uint16_t* A, const uint16_t* Wp, con
         const char* e = getenv("NEAT_GEMM_WIDE_SPLIT");              // 0: the unsplit 8-wave kernel (A/B runs)
         split = e ? atoi(e) : 1;
     }
-    if (split && K % (2 * R_BKH) == 0 && K >= 4 * R_BKH && cdiv(M, 64) <= wide_cus()) {
+    if (split && K % (2 * R_BKH) == 0 && K >= 4 * R_BKH && (cdiv(M, 64) <= wide_cus() || split == 2)) {
         if (epilogue == NEAT_EPI_BIAS_RES_F32)
             return launch_wide_split<W_RES>(A, Wp, bias, res, (float*)out0, nullptr, M, K, s, "neat_gemm_bf16(wide split, residual)");
         return launch_wide_split<W_BF16>(A, Wp, nullptr, nullptr, nullptr, (uint16_t*)out0, M, K, s, "neat_gemm_bf16(wide split, bf16)");

@@ -104,7 +104,7 @@ def test_ln_bwd_finalize_batched_equals_per_layer():
 
 # ------------------------------------------------------------------ GEMM
 SHAPES = [(300, 384, 128), (1000, 512, 512), (77 * 7, 2048, 512), (129, 16, 128), (512, 512, 2048), (77, 1536, 768),
-          (5000, 528, 384), (40000, 512, 512), (300, 512, 128)]
+          (5000, 528, 384), (40000, 512, 512), (300, 512, 128), (3000, 512, 1536)]
 
 
 def _kernels(N, K):
@@ -206,7 +206,8 @@ def test_gemm_exact_small_integers():
                                         # underfilled grids (packed text batches, a 250-image gallery batch): the
                                         # N = 512 ones run the 64 x 512-unit kernel of gemm_rowln.hip; ragged rows
                                         (11136 + 5, 512, 2048, "panel"), (14848, 512, 512, "panel"),
-                                        (12500, 768, 768, "panel"), (2000, 1536, 512, "panel")])
+                                        (12500, 768, 768, "panel"), (2000, 1536, 512, "panel"),
+                                        (16384 - 3, 512, 1536, "panel"), (16384 + 1, 512, 512, "panel")])
 def test_gemm_exact_at_full_size(M, N, K, kern):
     """Full-size launches (many units per workgroup, ragged rows, idle waves at N = 528, the c_fc shape) on
     small-integer operands: every bf16 output is exact, so a late or missing LDS piece cannot hide."""
