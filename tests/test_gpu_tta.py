@@ -508,6 +508,34 @@ def test_other_clip_configs_match_oracle(name):
     assert rel_l2(_flat_ln(model), flat_o) < 1e-3
 
 
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 5), (2, 3), (65, 2)])
+def test_tta_step_edge_batches_vs_oracle(B, N, packed):
+    """The smallest and the raggedest adaptation batches -- one caption row (the entropy softmax runs over a single
+    coarse image, the hinge and triplet sums over one row), a gallery of one image (every caption aligns to it), 65 rows
+    (one more than the 64-row tiles of the loss and coarse kernels) against 2 images -- one step against the fp32 oracle:
+    loss terms, coarse indices, score rows and the adapted LayerNorm parameters."""
+    name = "neat-tiny"
+    model, sd = _model(name, 0)
+    model.pack_tokens = packed
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    toks = synth.synth_caption_sets(B, t["context_length"], t["vocab_size"], 100 + B)
+    G = torch.nn.functional.normalize(torch.randn(N, cfg["embed_dim"], generator=torch.Generator().manual_seed(B + N)), dim=-1)
+    oc.freeze_parameters(model, False)
+    opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+    losses, idx, S = T.tta_step(model, opt, [x.to(DEV) for x in toks], G.to(DEV), 0.03, 0.07)
+    st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
+    lo, io, So, _, _ = O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)
+    assert tuple(S.shape) == (B, N) and tuple(idx.shape) == (B,)
+    assert torch.isfinite(losses).all()
+    torch.testing.assert_close(losses.cpu(), lo.float(), rtol=5e-3, atol=2e-3)
+    assert float((S.cpu() - So).abs().max()) < 5e-3
+    assert int((idx.cpu().long() != io).sum()) <= (0 if N == 1 else max(1, B // 20))
+    flat_o = torch.cat([sd[k].flatten() for k in O.adapted_param_names(sd)])
+    assert rel_l2(_flat_ln(model), flat_o) < 1e-3
+
+
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
