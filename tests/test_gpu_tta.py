@@ -682,6 +682,32 @@ def test_packed_tokens_equal_full_length(name, B):
     assert rel_l2(b["p"], a["p"]) < 1e-6
 
 
+@pytest.mark.parametrize("lens", [(60, 75), (75, 75), (1, 75)])
+def test_packed_tokens_with_full_length_captions(lens):
+    """Packed text batches at the long end: captions that fill the 77-token context (EOT at position 76, the truncation
+    case of the reference tokenizer), all of them or one-token captions next to full ones -- ViT-B-32, one step, against the
+    full-length run of the same step."""
+    name, B = "ViT-B-32", 5
+    cfg = synth.get_cfg(name)
+    t = cfg["text_cfg"]
+    toks = [x.to(DEV) for x in synth.synth_caption_sets(B, t["context_length"], t["vocab_size"], 41, *lens)]
+    assert int(max(x.argmax(dim=-1).max() for x in toks)) == lens[1] + 1
+    G = torch.nn.functional.normalize(torch.randn(9, cfg["embed_dim"], generator=torch.Generator().manual_seed(3)), dim=-1).to(DEV)
+    out = []
+    for packed in (False, True):
+        model, _ = _model(name, 0)
+        model.pack_tokens = packed
+        oc.freeze_parameters(model, False)
+        opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
+        losses, idx, S = T.tta_step(model, opt, toks, G, 0.03, 0.07)
+        out.append(dict(losses=losses.cpu(), idx=idx.cpu(), S=S.cpu(), p=_flat_ln(model)))
+    a, b = out
+    torch.testing.assert_close(a["losses"], b["losses"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(a["idx"], b["idx"])
+    assert float((a["S"] - b["S"]).abs().max()) < 1e-5
+    assert rel_l2(b["p"], a["p"]) < 1e-6
+
+
 def test_batch_plan_from_host_tokens_equals_the_device_plan():
     """train_one_epoch computes the packed layout from the tokens it still holds on the host (no device-to-host copy, so
     the host does not wait for the previous batch): the same cu_seqlens as the library's neat_pack_plan on the device
