@@ -283,6 +283,61 @@ __global__ __launch_bounds__(P_THREADS, 2 * OCC) void gemm_panel_kernel(
                                 }
                             }
                         }
+                    } else if constexpr (NI == 1) {
+                        // bf16 outputs of the 128 x 128 unit (a wave owns 16 columns): a row of the 16 x 16 tile is 32 B of
+                        // bf16 = two lanes of 8 columns, so one wave-instruction serves TWO row tiles: lanes 0..31 read
+                        // tile t from slab 0, lanes 32..63 tile t+1 from slab 1 (16-B chunks XOR-swizzled by row & 3).
+                        const int half = lane >> 5, er = (lane >> 1) & 15, eq = lane & 1;
+                        const int n = nt0 * 16 + eq * 8;
+                        const char* rd = stg + half * SLAB2 + er * 64;
+                        const int c0 = ((2 * eq) ^ (er & 3)) << 4, c1 = ((2 * eq + 1) ^ (er & 3)) << 4;
+                        char* wr = stg + fr * 64 + ((fq ^ (fr & 3)) << 4);
+                        constexpr bool PREFETCH_H = FULL && EPI == NEAT_EPI_GELU_BWD;
+                        uint4 hpre[4];
+                        if constexpr (PREFETCH_H) {
+#pragma unroll
+                            for (int tp = 0; tp < 4; ++tp)
+                                hpre[tp] = *reinterpret_cast<const uint4*>(aux + (long)(rowm0 + (2 * tp + half) * 16 + er) * N + n);
+                        }
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            *reinterpret_cast<f32x4*>(wr) = acc[0][2 * tp];
+                            *reinterpret_cast<f32x4*>(wr + SLAB2) = acc[0][2 * tp + 1];
+                            const float4 a0 = *reinterpret_cast<const float4*>(rd + c0);
+                            const float4 a1 = *reinterpret_cast<const float4*>(rd + c1);
+                            const int m = rowm0 + (2 * tp + half) * 16 + er;
+                            if constexpr (!FULL) {
+                                if (m >= M) continue;
+                            }
+                            const long o = (long)m * N + n;
+                            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                            if constexpr (EPI == NEAT_EPI_BF16 || EPI == NEAT_EPI_BIAS_BF16) {
+                                *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(
+                                    pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                            } else if constexpr (EPI == NEAT_EPI_BIAS_GELU) {
+                                uint32_t hp[4], up[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    hp[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                    up[q] = pack2bf(quick_gelu(h0), quick_gelu(h1));
+                                }
+                                if (out0) *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                                *reinterpret_cast<uint4*>((bf16_t*)out1 + o) = make_uint4(up[0], up[1], up[2], up[3]);
+                            } else {  // NEAT_EPI_GELU_BWD
+                                uint4 hq;
+                                if constexpr (PREFETCH_H) hq = hpre[tp];
+                                else hq = *reinterpret_cast<const uint4*>(aux + o);
+                                const uint32_t hp[4] = {hq.x, hq.y, hq.z, hq.w};
+                                uint32_t dp[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float h0 = __uint_as_float(hp[q] << 16), h1 = __uint_as_float(hp[q] & 0xffff0000u);
+                                    dp[q] = pack2bf(v[2 * q] * quick_gelu_grad(h0), v[2 * q + 1] * quick_gelu_grad(h1));
+                                }
+                                *reinterpret_cast<uint4*>((bf16_t*)out0 + o) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+                            }
+                        }
                     } else {
                         // bf16 outputs: a lane owns 8 columns (16 B of bf16), 4 lanes cover the wave's 32 columns,
                         // one wave-instruction covers the whole 16-row tile.  Slab swizzle sw(r) is conflict-free
@@ -424,6 +479,18 @@ static int launch_gemm_c(const uint16_t* A, const uint16_t* Wp, const float* bia
     return NEAT_OK;
 }
 
+// The 128 x 128 unit (NI = 1: a wave owns 16 columns) is taken for the fp32 residual epilogue when the 128 x 256 units
+// would fill less than this fraction (percent) of the 2-per-CU workgroup slots.  NEAT_GEMM_NARROW_FILL overrides it
+// (0 = never; 1000 + p = for every epilogue at p percent, the form that was measured and not kept).
+static int narrow_fill_percent() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NEAT_GEMM_NARROW_FILL");
+        v = e ? atoi(e) : 80;
+    }
+    return v;
+}
+
 template <int EPI>
 static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias, const float* res,
                        const uint16_t* aux, void* out0, void* out1, int M, int N, int K, hipStream_t s) {
@@ -432,6 +499,18 @@ static int launch_gemm(const uint16_t* A, const uint16_t* Wp, const float* bias,
     // N = 512 at no more than one unit per CU (packed text batches, the MCQ scorer): the 64 x 512-unit kernel
     if (gemm_wide512_applies(M, N, K, EPI))
         return launch_gemm_wide512(EPI, A, Wp, bias, res, out0, M, K, s);
+    // Small residual GEMMs at N = 768 / 1024 (the MCQ scorer's vision tower at 12 608 rows, packed ViT-L-14 text batches):
+    // 128 x 256 units leave the second workgroup slot of most CUs empty (99 x 3 = 297 units on 512 slots), i.e. eight waves
+    // per CU.  As 128 x 128 units they are twice as many, sixteen waves on most CUs: MCQ batch 6.05 -> 5.79 ms, ViT-L-14
+    // packed step 27.4 -> 26.5 ms.  Only this epilogue: the bf16 ones lose 1-2 us per launch with the narrow unit (their
+    // slab serves two row tiles per instruction), which cancelled the gain when every epilogue took it.
+    if ((EPI == NEAT_EPI_BIAS_RES_F32 || narrow_fill_percent() >= 1000) &&
+        units * 100 < (long)(narrow_fill_percent() % 1000) * 2 * cus && N % 128 == 0) {
+        const long units1 = (long)cdiv(M, 128) * cdiv(N, P_WAVES * 16);
+        const long want1 = (units1 + 7) / 8 * 8;
+        const int grid1 = (int)(want1 < 2 * cus ? want1 : 2 * cus);
+        return launch_gemm_c<EPI, P_BKH, 1, 2>(A, Wp, bias, res, aux, out0, out1, M, N, K, grid1, s);
+    }
     // persistent: two workgroups per CU; a multiple of 8 so that the XCD-aware deal applies
     const long want = (units + 7) / 8 * 8;
     const int grid = (int)(want < 2 * cus ? want : 2 * cus);
