@@ -536,32 +536,54 @@ def cpu_baseline(a, cfg):
     share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
     cores = min(avail, share) if share > 0 else avail
     torch.set_num_threads(cores)
-    sd = synth.synth_state_dict(a.model, 0)
     t = cfg["text_cfg"]
     Bc = a.cpu_sample
-    toks = synth.synth_caption_sets(Bc, t["context_length"], t["vocab_size"], 1000)
-    G = torch.nn.functional.normalize(torch.randn(64, cfg["embed_dim"], generator=torch.Generator().manual_seed(7)), dim=-1)
+    # The sample's weights and data.  For ViT-B-32 (the headline model) it is the non-degenerate parity fixture of
+    # tests/golden/make_spread_weights.py: "spread" weights (features far from collinear) and RELATED caption sets whose
+    # row r describes image r, with the gallery = those images through the vision tower of either leg -- so recall@1 is
+    # far from chance and the comparison below means something.  Other models have no fitted projections: seeded random
+    # weights, independent caption sets and a random unit gallery (recall@1 at chance; the loss terms still compare).
+    spread = a.model == "ViT-B-32" and Bc <= 256 and os.path.exists(
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "spread_vitb32.npz"))
+    if spread:
+        sd = synth.spread_state_dict(a.model, 0)
+        toks = tuple(x[:Bc] for x in synth.synth_related_caption_sets(256, t["context_length"], t["vocab_size"], 4321))
+        images = synth.synth_images(256, cfg["vision_cfg"]["image_size"], 4322)[:Bc]
+        G = torch.cat([O.encode_image_fwd(sd, images[i:i + 32], True) for i in range(0, Bc, 32)])      # untimed
+        n_gal = Bc
+    else:
+        sd = synth.synth_state_dict(a.model, 0)
+        toks = synth.synth_caption_sets(Bc, t["context_length"], t["vocab_size"], 1000)
+        n_gal = 64
+        G = torch.nn.functional.normalize(torch.randn(n_gal, cfg["embed_dim"], generator=torch.Generator().manual_seed(7)), dim=-1)
+    sd0 = {k: v.clone() for k, v in sd.items()}                      # the oracle's step updates sd in place
     st = O.AdamWState({k: sd[k] for k in O.adapted_param_names(sd)})
     t0 = time.perf_counter()
     for _ in range(a.tta_steps):
         losses_c, idx_c, S_c = O.tta_step(sd, st, toks, G, 2e-4, 1e-3, 0.03, 0.07)[:3]
     dt = time.perf_counter() - t0
     out = dict(value=round(Bc / dt, 3), unit="pairs/s", cores=cores, cores_visible=avail, kind="port",
-               sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, {a.model}, fp32 torch CPU oracle, "
-                      f"{dt:.1f} s")
-    # the same sample through the HIP path: recall@1 of both legs on the produced score rows (synthetic ground
-    # truth: caption r <-> gallery item r % 64) and how often their top-1 items agree
+               sample=f"1 batch of {Bc} caption rows x {a.tta_steps} steps, gallery {n_gal}, {a.model}, fp32 torch CPU "
+                      f"oracle, {dt:.1f} s" + ("; spread weights + related captions (tests/golden/make_spread_weights.py), "
+                                               "gallery = the captions' images through each leg's vision tower" if spread else ""))
+    # the same sample through the HIP path: recall@1 of both legs on the produced score rows (ground truth: caption r <->
+    # gallery item r % n_gal) and how often their top-1 items agree
     from neat_amd import open_clip as oc, train_TTA as T
     from neat_amd.optim import AdamW
     dev = torch.device("cuda", torch.cuda.current_device())
     model = oc.create_model(a.model, device=dev)
-    model.load_state_dict(synth.synth_state_dict(a.model, 0), strict=True)
+    model.load_state_dict(sd0, strict=True)
+    if spread:
+        with torch.no_grad():
+            G_d = model.encode_image(images.to(dev), normalize=True)
+    else:
+        G_d = G.to(dev)
     oc.freeze_parameters(model, False)
     opt = AdamW(oc.collect_params(model, False)[0], lr=2e-4, weight_decay=1e-3)
     toks_d = [x.to(dev) for x in toks]
     for _ in range(a.tta_steps):
-        losses_g, idx_g, S_g = T.tta_step(model, opt, toks_d, G.to(dev), 0.03, 0.07)
-    truth = torch.arange(Bc) % 64
+        losses_g, idx_g, S_g = T.tta_step(model, opt, toks_d, G_d, 0.03, 0.07)
+    truth = torch.arange(Bc) % n_gal
     S_g = S_g.float().cpu()
     out["recall_at_1"] = dict(gpu=round(float((S_g.argmax(1) == truth).float().mean()), 4),
                               cpu=round(float((S_c.argmax(1) == truth).float().mean()), 4),
@@ -574,7 +596,8 @@ def cpu_baseline(a, cfg):
                               loss_terms_cpu=[round(float(x), 6) for x in losses_c],
                               loss_term_rel_diff=[round(abs(float(g_) - float(c_)) / max(abs(float(c_)), 1e-12), 6)
                                                   for g_, c_ in zip(losses_g.tolist(), losses_c)],
-                              coarse_idx_mismatch=int((idx_g.cpu().long() != idx_c).sum()))
+                              coarse_idx_mismatch=int((idx_g.cpu().long() != idx_c).sum()),
+                              weights="spread" if spread else "seeded random (collinear features: recall@1 at chance)")
     return out
 
 
